@@ -1,0 +1,167 @@
+/*
+ * mkckks.h -- C-ABI of libmkckks_hip.so, the MI355X (gfx950) engine for the
+ * multikey-CKKS PRE + aggregation hot path of CDACHPCIE25/PPQSFLHE.
+ *
+ * The reference has no FFI/plugin layer: its hot path is eight C++ main()s that
+ * call OpenFHE's CryptoContext.  The drop-in boundary is
+ * therefore (1) the CLI/JSON contract, re-created by the C++ hosts under
+ * ppqsflhe_amd/host/, and (2) this library, whose entry points replace the
+ * OpenFHE calls those mains make.  Each entry point cites the reference
+ * call site(s) it stands in for (paths relative to /root/reference).
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative MKCKKS_E_* code otherwise,
+ *    never throws across the ABI; mkckks_last_error() gives the message of the
+ *    calling thread's last failure.
+ *  - "d_" pointers are DEVICE pointers (HBM) owned by the caller (hipMalloc,
+ *    torch tensor data_ptr(), or mkckks_dev_alloc); "h_" pointers are host.
+ *  - all work is enqueued on the context's HIP stream (mkckks_set_stream) and is
+ *    asynchronous w.r.t. the host unless stated; a context is re-entrant per
+ *    (context, stream) pair, not across threads sharing one context.
+ *  - polynomials are limb-major uint64: a polynomial over the first nl Q-limbs
+ *    is u64[nl][N]; a ciphertext is u64[2][nl][N] (c0 then c1); a batch is
+ *    u64[n_ct][2][nl][N]; over QP the limb order is q_0..q_{L-1},p_0..p_{K-1};
+ *    a public key is u64[2][D][N] (b then a); an eval (re-encryption) key is
+ *    u64[beta][2][D][N] (digit j: b_j then a_j).  EVALUATION format = negacyclic
+ *    NTT, natural-order input, bit-reversed output, psi = minimal primitive
+ *    2N-th root (what OpenFHE serialises with "f":0).
+ */
+#ifndef MKCKKS_H
+#define MKCKKS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MKCKKS_OK 0
+#define MKCKKS_E_INVALID (-1)   /* bad argument / unsupported parameter set   */
+#define MKCKKS_E_NODEVICE (-2)  /* no HIP device, or host-only context used   */
+#define MKCKKS_E_HIP (-3)       /* HIP runtime error (message has the detail) */
+#define MKCKKS_E_NOMEM (-4)
+#define MKCKKS_E_INTERNAL (-5)
+
+typedef struct mkckks_ctx mkckks_ctx;
+
+/* server/config/config_cc.json:2-5 knobs + the ones genCC.cpp leaves at
+ * OpenFHE defaults (first mod 60, aux 60, extra 20: CC.json 'ab','eb'). */
+typedef struct mkckks_params {
+    uint32_t log_n;        /* ring dimension N = 2^log_n (CC.json "rd")            */
+    uint32_t mult_depth;   /* MultiplicativeDepth; #Q limbs L = mult_depth + 2     */
+    uint32_t scaling_bits; /* ScalingModSize                                       */
+    uint32_t first_bits;   /* FirstModSize (60)                                    */
+    uint32_t dnum;         /* NumLargeDigits of HYBRID key switching ("dnum")      */
+    uint32_t aux_bits;     /* auxiliary prime size ("ab", 60)                      */
+    uint32_t extra_bits;   /* FLEXIBLEAUTOEXT extra limb size ("eb", 20)           */
+    int32_t device;        /* HIP device ordinal; -1 = host-only (tables, no GPU)  */
+} mkckks_params;
+
+typedef struct mkckks_info {
+    uint32_t ring_dim, num_q, num_p, alpha, beta, slots;
+} mkckks_info;
+
+const char *mkckks_last_error(void);
+const char *mkckks_version(void);
+
+/* ---- context -------------------------------------------------------------
+ * replaces GenCryptoContext(params)+Enable(...) (server/src/genCC.cpp:68-76)
+ * and Serial::DeserializeFromFile(cc) (server/src/changeCipherDomain.cpp:33,
+ * aggregateEncryptedWeights.cpp:47 and the client mains): builds Q, P, roots,
+ * twiddles and all CRT tables and keeps them resident in HBM. */
+int mkckks_ctx_create(const mkckks_params *p, mkckks_ctx **out);
+int mkckks_ctx_destroy(mkckks_ctx *c);
+int mkckks_ctx_info(const mkckks_ctx *c, mkckks_info *out);
+int mkckks_ctx_moduli(const mkckks_ctx *c, uint64_t *h_out /*D*/);
+int mkckks_ctx_roots(const mkckks_ctx *c, uint64_t *h_out /*D*/);
+/* CryptoParametersCKKSRNS::GetScalingFactorReal / RealBig (level = #dropped limbs) */
+int mkckks_scaling_factor(const mkckks_ctx *c, uint32_t level, int big, double *out);
+/* stream: a hipStream_t passed as void* (NULL = default stream) */
+int mkckks_set_stream(mkckks_ctx *c, void *hip_stream);
+int mkckks_sync(mkckks_ctx *c);
+
+/* ---- device memory helpers (so hosts need no HIP headers) ---------------- */
+int mkckks_dev_alloc(mkckks_ctx *c, size_t bytes, void **d_out);
+int mkckks_dev_free(mkckks_ctx *c, void *d_ptr);
+int mkckks_upload(mkckks_ctx *c, void *d_dst, const void *h_src, size_t bytes);   /* synchronous */
+int mkckks_download(mkckks_ctx *c, void *h_dst, const void *d_src, size_t bytes); /* synchronous */
+
+/* ---- transforms: DCRTPoly::SetFormat (OpenFHE ChineseRemainderTransformFTT)
+ * d_polys is u64[n_polys][nl(+K)][N], transformed in place.  with_p != 0 means
+ * each polynomial carries the K P-limbs after its nl Q-limbs. */
+int mkckks_ntt_forward_batch(mkckks_ctx *c, uint64_t *d_polys, uint32_t n_polys, uint32_t nl, int with_p);
+int mkckks_ntt_inverse_batch(mkckks_ctx *c, uint64_t *d_polys, uint32_t n_polys, uint32_t nl, int with_p);
+
+/* ---- cc->EvalAdd(ct1, ct2)  (aggregateEncryptedWeights.cpp:82,91,106) ---- */
+int mkckks_eval_add_batch(mkckks_ctx *c, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out,
+                          uint32_t n_ct, uint32_t nl);
+/* n-client generalisation of the same loop: d_out[b] = sum_k d_in[k][b], d_in is
+ * u64[n_clients][n_ct][2][nl][N]. */
+int mkckks_eval_sum_batch(mkckks_ctx *c, const uint64_t *d_in, uint64_t *d_out, uint32_t n_clients,
+                          uint32_t n_ct, uint32_t nl);
+
+/* ---- cc->EvalMult(ct, operand) on a noiseScaleDeg-2 ciphertext
+ * (aggregateEncryptedWeights.cpp:83,92,107: EvalMult(ct_sum, 0.5)): rescale
+ * (drop limb nl-1) then multiply by round(operand * sf(level+1)).
+ * in u64[n_ct][2][nl][N] at `level` -> out u64[n_ct][2][nl-1][N]. */
+int mkckks_rescale_mult_const_batch(mkckks_ctx *c, const uint64_t *d_in, uint64_t *d_out, uint32_t n_ct,
+                                    uint32_t nl, double operand);
+/* the two halves on their own (ModReduceInternalInPlace / EvalMultCoreInPlace) */
+int mkckks_rescale_batch(mkckks_ctx *c, const uint64_t *d_in, uint64_t *d_out, uint32_t n_ct, uint32_t nl);
+int mkckks_mult_const_batch(mkckks_ctx *c, uint64_t *d_ct, uint32_t n_ct, uint32_t nl, double operand);
+
+/* ---- cc->ReEncrypt(ct, reKey)  (changeCipherDomain.cpp:74,89,105) --------
+ * INDCPA proxy re-encryption = hybrid key switch of c1 with the eval key:
+ * out = (c0 + <d,b>/P, <d,a>/P).  d_evk is u64[beta][2][D][N] (full level);
+ * ciphertexts have nl <= L limbs; in/out may alias. */
+int mkckks_reencrypt_batch(mkckks_ctx *c, const uint64_t *d_ct, const uint64_t *d_evk, uint64_t *d_out,
+                           uint32_t n_ct, uint32_t nl);
+/* stages of the above, exposed for parity tests and profiling:
+ * KeySwitchHYBRID::EvalKeySwitchPrecomputeCore: c1 u64[n][nl][N] ->
+ * digits u64[n][nparts][nl+K][N]; ApproxModDown: u64[n][nl+K][N] -> u64[n][nl][N]. */
+int mkckks_modup_batch(mkckks_ctx *c, const uint64_t *d_c1, uint64_t *d_digits, uint32_t n, uint32_t nl);
+int mkckks_moddown_batch(mkckks_ctx *c, const uint64_t *d_in, uint64_t *d_out, uint32_t n, uint32_t nl);
+
+/* ---- cc->KeyGen()  (client/src/keyGen.cpp:33) -----------------------------
+ * randomness is supplied by the caller (host samplers in ppqsflhe_amd/host, or
+ * a test's seeded vectors): s ternary int8[N], e int32[N] (COEFFICIENT),
+ * a u64[D][N] uniform residues (taken as EVALUATION).
+ * d_pk out u64[2][D][N], d_sk out u64[D][N] (EVALUATION). */
+int mkckks_keygen(mkckks_ctx *c, const int8_t *d_s, const uint64_t *d_a, const int32_t *d_e,
+                  uint64_t *d_pk, uint64_t *d_sk);
+/* ---- cc->ReKeyGen(mySk, peerPk)  (client/src/REkeyGen.cpp:52) -------------
+ * s_old int8[N]; u int8[beta][N]; e0,e1 int32[beta][N]; d_evk out u64[beta][2][D][N]. */
+int mkckks_rekeygen(mkckks_ctx *c, const int8_t *d_s_old, const uint64_t *d_pk_new, const int8_t *d_u,
+                    const int32_t *d_e0, const int32_t *d_e1, uint64_t *d_evk);
+
+/* ---- cc->Encrypt(pk, pt)  (client/src/encryptModelWeights.cpp:83,91,110) --
+ * d_pt u64[n_ct][nl][N] encoded plaintexts (EVALUATION); v int8[n_ct][N];
+ * e0,e1 int32[n_ct][N]; out u64[n_ct][2][nl][N]. */
+int mkckks_encrypt_batch(mkckks_ctx *c, const uint64_t *d_pk, const uint64_t *d_pt, const int8_t *d_v,
+                         const int32_t *d_e0, const int32_t *d_e1, uint64_t *d_ct, uint32_t n_ct, uint32_t nl);
+/* scaled real coefficient vectors -> residues in EVALUATION format over nl limbs
+ * (the integer half of CKKSPackedEncoding::Encode; the fp64 canonical embedding
+ * is host code in ppqsflhe_amd/host/codec.hpp).  Each double (|x| < 2^120) is
+ * rounded to the nearest integer (ties away from zero) and that integer is
+ * reduced exactly per limb: coef double[n][N] -> u64[n][nl][N]. */
+int mkckks_lift_ntt_batch(mkckks_ctx *c, const double *d_coef, uint64_t *d_out, uint32_t n, uint32_t nl);
+
+/* ---- cc->Decrypt(sk, ct, &pt)  (client/src/decryptModelWeights.cpp:81,90,108)
+ * DecryptCore: m = INTT(c0 + c1*s); d_m out u64[n_ct][nl][N] (COEFFICIENT).
+ * CRT interpolation + Decode run on the host (codec.hpp). */
+int mkckks_decrypt_batch(mkckks_ctx *c, const uint64_t *d_ct, const uint64_t *d_sk, uint64_t *d_m,
+                         uint32_t n_ct, uint32_t nl);
+
+/* ---- multi-GPU aggregation step (new) -----------------------
+ * after an RCCL ncclSum over uint64 of `n_terms` canonical residues per word,
+ * reduce every word mod its limb modulus: d_ct u64[n_ct][2][nl][N] in place. */
+int mkckks_reduce_mod_batch(mkckks_ctx *c, uint64_t *d_ct, uint32_t n_ct, uint32_t nl, uint32_t n_terms);
+
+/* ---- introspection for tests: copy a CRT table to the host ---------------- */
+int mkckks_ctx_twiddles(const mkckks_ctx *c, uint32_t limb, int inverse, uint64_t *h_out /*N*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MKCKKS_H */

@@ -1,0 +1,277 @@
+"""ctypes binding of libmkckks_hip.so (C-ABI: include/mkckks.h).
+
+Mirrors, for the hot path only, the OpenFHE CryptoContext calls the reference's
+C++ mains make:
+    cc->ReEncrypt(ct, reKey)          -> Context.reencrypt          changeCipherDomain.cpp:74
+    cc->EvalAdd(ct1, ct2)             -> Context.eval_add           aggregateEncryptedWeights.cpp:82
+    cc->EvalMult(ct, 0.5)             -> Context.rescale_mult_const aggregateEncryptedWeights.cpp:83
+    cc->KeyGen() / ReKeyGen / Encrypt / Decrypt -> keygen / rekeygen / encrypt / decrypt
+Buffers are DeviceBuffer objects (HBM, limb-major uint64) or anything with a
+``data_ptr()`` (a torch tensor on the GPU).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libmkckks_hip.so")
+
+
+class MkckksError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mkckks error {code}: {msg}")
+        self.code = code
+
+
+class _Params(C.Structure):
+    _fields_ = [("log_n", C.c_uint32), ("mult_depth", C.c_uint32), ("scaling_bits", C.c_uint32),
+                ("first_bits", C.c_uint32), ("dnum", C.c_uint32), ("aux_bits", C.c_uint32),
+                ("extra_bits", C.c_uint32), ("device", C.c_int32)]
+
+
+class _Info(C.Structure):
+    _fields_ = [("ring_dim", C.c_uint32), ("num_q", C.c_uint32), ("num_p", C.c_uint32),
+                ("alpha", C.c_uint32), ("beta", C.c_uint32), ("slots", C.c_uint32)]
+
+
+# every symbol include/mkckks.h declares: name -> (restype, argtypes)
+_vp, _u32, _u64p, _sz, _int, _dbl = C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_int, C.c_double
+SYMBOLS = {
+    "mkckks_last_error": (C.c_char_p, []),
+    "mkckks_version": (C.c_char_p, []),
+    "mkckks_ctx_create": (_int, [C.POINTER(_Params), C.POINTER(_vp)]),
+    "mkckks_ctx_destroy": (_int, [_vp]),
+    "mkckks_ctx_info": (_int, [_vp, C.POINTER(_Info)]),
+    "mkckks_ctx_moduli": (_int, [_vp, _u64p]),
+    "mkckks_ctx_roots": (_int, [_vp, _u64p]),
+    "mkckks_scaling_factor": (_int, [_vp, _u32, _int, C.POINTER(_dbl)]),
+    "mkckks_set_stream": (_int, [_vp, _vp]),
+    "mkckks_sync": (_int, [_vp]),
+    "mkckks_dev_alloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
+    "mkckks_dev_free": (_int, [_vp, _vp]),
+    "mkckks_upload": (_int, [_vp, _vp, _vp, _sz]),
+    "mkckks_download": (_int, [_vp, _vp, _vp, _sz]),
+    "mkckks_ntt_forward_batch": (_int, [_vp, _vp, _u32, _u32, _int]),
+    "mkckks_ntt_inverse_batch": (_int, [_vp, _vp, _u32, _u32, _int]),
+    "mkckks_eval_add_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32]),
+    "mkckks_eval_sum_batch": (_int, [_vp, _vp, _vp, _u32, _u32, _u32]),
+    "mkckks_rescale_mult_const_batch": (_int, [_vp, _vp, _vp, _u32, _u32, _dbl]),
+    "mkckks_rescale_batch": (_int, [_vp, _vp, _vp, _u32, _u32]),
+    "mkckks_mult_const_batch": (_int, [_vp, _vp, _u32, _u32, _dbl]),
+    "mkckks_reencrypt_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32]),
+    "mkckks_modup_batch": (_int, [_vp, _vp, _vp, _u32, _u32]),
+    "mkckks_moddown_batch": (_int, [_vp, _vp, _vp, _u32, _u32]),
+    "mkckks_keygen": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "mkckks_rekeygen": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mkckks_encrypt_batch": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32]),
+    "mkckks_lift_ntt_batch": (_int, [_vp, _vp, _vp, _u32, _u32]),
+    "mkckks_decrypt_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32]),
+    "mkckks_reduce_mod_batch": (_int, [_vp, _vp, _u32, _u32, _u32]),
+    "mkckks_ctx_twiddles": (_int, [_vp, _u32, _int, _u64p]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _LIB
+
+
+def load_library():
+    """Load the in-tree HIP library; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise ImportError(
+                f"{_LIB} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C ppqsflhe_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(_LIB)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if hasattr(x, "data_ptr"):  # torch tensor on the device
+        return x.data_ptr()
+    if isinstance(x, int):
+        return x
+    raise TypeError(f"expected a device buffer, got {type(x)}")
+
+
+class DeviceBuffer:
+    """A typed, shaped view of HBM owned by a Context."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        ctx._check(ctx._L.mkckks_dev_alloc(ctx._h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        self._owned = True
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert arr.nbytes == self.nbytes, (arr.shape, self.shape)
+        self.ctx._check(self.ctx._L.mkckks_upload(self.ctx._h, self.ptr, arr.ctypes.data, self.nbytes))
+        return self
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.ctx._check(self.ctx._L.mkckks_download(self.ctx._h, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def view(self, offset_elems, shape):
+        """A non-owning sub-view (element offset) of this buffer."""
+        v = object.__new__(DeviceBuffer)
+        v.ctx, v.shape, v.dtype = self.ctx, tuple(shape), self.dtype
+        v.nbytes = int(np.prod(v.shape, dtype=np.int64)) * v.dtype.itemsize
+        v.ptr = self.ptr + offset_elems * self.dtype.itemsize
+        v._owned = False
+        v._parent = self
+        return v
+
+    def free(self):
+        if getattr(self, "_owned", False) and self.ptr and self.ctx._h:
+            self.ctx._L.mkckks_dev_free(self.ctx._h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """Device-resident CKKS context (moduli, twiddles, CRT tables in HBM)."""
+
+    def __init__(self, log_n, mult_depth, scaling_bits, first_bits=60, dnum=3, aux_bits=60, extra_bits=20,
+                 device=0):
+        self._L = load_library()
+        self._h = None
+        p = _Params(log_n, mult_depth, scaling_bits, first_bits, dnum, aux_bits, extra_bits, device)
+        h = C.c_void_p()
+        self._check(self._L.mkckks_ctx_create(C.byref(p), C.byref(h)))
+        self._h = h.value
+        info = _Info()
+        self._check(self._L.mkckks_ctx_info(self._h, C.byref(info)))
+        self.N, self.L, self.K = info.ring_dim, info.num_q, info.num_p
+        self.D = self.L + self.K
+        self.alpha, self.beta, self.slots = info.alpha, info.beta, info.slots
+        self.device = device
+        self.moduli = np.zeros(self.D, dtype=np.uint64)
+        self.roots = np.zeros(self.D, dtype=np.uint64)
+        self._check(self._L.mkckks_ctx_moduli(self._h, self.moduli.ctypes.data))
+        self._check(self._L.mkckks_ctx_roots(self._h, self.roots.ctypes.data))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MkckksError(rc, self._L.mkckks_last_error().decode())
+
+    def close(self):
+        if self._h:
+            self._L.mkckks_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters
+    def sf(self, level):
+        out = C.c_double()
+        self._check(self._L.mkckks_scaling_factor(self._h, level, 0, C.byref(out)))
+        return out.value
+
+    def sf_big(self, level):
+        out = C.c_double()
+        self._check(self._L.mkckks_scaling_factor(self._h, level, 1, C.byref(out)))
+        return out.value
+
+    def twiddles(self, limb, inverse=False):
+        out = np.zeros(self.N, dtype=np.uint64)
+        self._check(self._L.mkckks_ctx_twiddles(self._h, limb, int(inverse), out.ctypes.data))
+        return out
+
+    def num_parts(self, nl):
+        return min(self.beta, -(-nl // self.alpha))
+
+    # ---- memory / stream
+    def empty(self, shape, dtype=np.uint64):
+        return DeviceBuffer(self, shape, dtype)
+
+    def to_device(self, arr, dtype=None):
+        arr = np.ascontiguousarray(arr, dtype=dtype or arr.dtype)
+        return DeviceBuffer(self, arr.shape, arr.dtype).upload(arr)
+
+    def set_stream(self, stream_handle):
+        self._check(self._L.mkckks_set_stream(self._h, stream_handle))
+
+    def sync(self):
+        self._check(self._L.mkckks_sync(self._h))
+
+    # ---- transforms (in place)
+    def ntt_forward(self, d_polys, n_polys, nl, with_p=False):
+        self._check(self._L.mkckks_ntt_forward_batch(self._h, _ptr(d_polys), n_polys, nl, int(with_p)))
+
+    def ntt_inverse(self, d_polys, n_polys, nl, with_p=False):
+        self._check(self._L.mkckks_ntt_inverse_batch(self._h, _ptr(d_polys), n_polys, nl, int(with_p)))
+
+    # ---- aggregation
+    def eval_add(self, a, b, out, n_ct, nl):
+        self._check(self._L.mkckks_eval_add_batch(self._h, _ptr(a), _ptr(b), _ptr(out), n_ct, nl))
+
+    def eval_sum(self, inp, out, n_clients, n_ct, nl):
+        self._check(self._L.mkckks_eval_sum_batch(self._h, _ptr(inp), _ptr(out), n_clients, n_ct, nl))
+
+    def rescale_mult_const(self, inp, out, n_ct, nl, operand):
+        self._check(self._L.mkckks_rescale_mult_const_batch(self._h, _ptr(inp), _ptr(out), n_ct, nl, float(operand)))
+
+    def rescale(self, inp, out, n_ct, nl):
+        self._check(self._L.mkckks_rescale_batch(self._h, _ptr(inp), _ptr(out), n_ct, nl))
+
+    def mult_const(self, ct, n_ct, nl, operand):
+        self._check(self._L.mkckks_mult_const_batch(self._h, _ptr(ct), n_ct, nl, float(operand)))
+
+    def reduce_mod(self, ct, n_ct, nl, n_terms):
+        self._check(self._L.mkckks_reduce_mod_batch(self._h, _ptr(ct), n_ct, nl, n_terms))
+
+    # ---- proxy re-encryption
+    def reencrypt(self, ct, evk, out, n_ct, nl):
+        self._check(self._L.mkckks_reencrypt_batch(self._h, _ptr(ct), _ptr(evk), _ptr(out), n_ct, nl))
+
+    def modup(self, c1, digits, n, nl):
+        self._check(self._L.mkckks_modup_batch(self._h, _ptr(c1), _ptr(digits), n, nl))
+
+    def moddown(self, inp, out, n, nl):
+        self._check(self._L.mkckks_moddown_batch(self._h, _ptr(inp), _ptr(out), n, nl))
+
+    # ---- keys and client endpoints
+    def keygen(self, s, a, e, pk, sk):
+        self._check(self._L.mkckks_keygen(self._h, _ptr(s), _ptr(a), _ptr(e), _ptr(pk), _ptr(sk)))
+
+    def rekeygen(self, s_old, pk_new, u, e0, e1, evk):
+        self._check(self._L.mkckks_rekeygen(self._h, _ptr(s_old), _ptr(pk_new), _ptr(u), _ptr(e0), _ptr(e1), _ptr(evk)))
+
+    def encrypt(self, pk, pt, v, e0, e1, ct, n_ct, nl):
+        self._check(self._L.mkckks_encrypt_batch(self._h, _ptr(pk), _ptr(pt), _ptr(v), _ptr(e0), _ptr(e1), _ptr(ct),
+                                                 n_ct, nl))
+
+    def lift_ntt(self, coef, out, n, nl):
+        self._check(self._L.mkckks_lift_ntt_batch(self._h, _ptr(coef), _ptr(out), n, nl))
+
+    def decrypt(self, ct, sk, m, n_ct, nl):
+        self._check(self._L.mkckks_decrypt_batch(self._h, _ptr(ct), _ptr(sk), _ptr(m), n_ct, nl))

@@ -1,0 +1,893 @@
+// engine.hip -- gfx950 kernels + launch sequences for the PRE / aggregation hot path.
+//
+// Reference call sites replaced (paths relative to /root/reference; OpenFHE internals
+// are [upstream]):
+//   changeCipherDomain.cpp:74,89,105        cc->ReEncrypt       -> Engine::reencrypt
+//   aggregateEncryptedWeights.cpp:82,91,106 cc->EvalAdd         -> Engine::eval_add / eval_sum
+//   aggregateEncryptedWeights.cpp:83,92,107 cc->EvalMult(.,0.5) -> Engine::rescale (+ factors)
+//   encryptModelWeights.cpp:83,91,110       cc->Encrypt         -> Engine::encrypt (+ lift_ntt)
+//   decryptModelWeights.cpp:81,90,108       cc->Decrypt         -> Engine::decrypt
+//   keyGen.cpp:33 / REkeyGen.cpp:52         KeyGen / ReKeyGen   -> Engine::keygen / rekeygen
+//
+// Data layout in HBM: limb-major u64, one limb = N contiguous words, so every kernel
+// streams 8-B (or 16-B) words with unit stride per lane; the limb (modulus) is uniform per
+// workgroup (blockIdx.y), so all per-limb constants sit in SGPRs.
+#include "engine.hpp"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace mk {
+
+// =====================================================================================
+// NTT kernels (schedule described in ntt_kernels.hpp)
+// =====================================================================================
+
+struct NttIo {
+    const u64 *in;
+    u64 *out;
+    size_t in_stride, out_stride;  // words between consecutive polynomials
+    uint32_t in_slot0, out_slot0;  // first limb slot touched inside a polynomial
+    uint32_t vslot0;               // virtual slot of the first limb (decides the limb id)
+    uint32_t nslots;               // limbs per polynomial handled by this launch
+    uint32_t nl;                   // #Q limbs of the polynomial (slots >= nl are P limbs)
+};
+
+__device__ __forceinline__ uint32_t limb_id_of(uint32_t vslot, uint32_t nl, uint32_t L) {
+    return vslot < nl ? vslot : L + (vslot - nl);
+}
+
+template <bool INV>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_col(NttIo io, NttTables T, const u64 *scale,
+                                                         const u64 *scale_sh) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const uint32_t poly = blockIdx.y / io.nslots, s = blockIdx.y % io.nslots;
+    const uint32_t id = limb_id_of(io.vslot0 + s, io.nl, T.L);
+    const LimbConst lc = T.limb[id];
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1, r2 = 1u << T.log_r2;
+    const u64 *src = io.in + (size_t)poly * io.in_stride + (size_t)(io.in_slot0 + s) * n;
+    u64 *dst = io.out + (size_t)poly * io.out_stride + (size_t)(io.out_slot0 + s) * n;
+    const uint32_t c0 = blockIdx.x * NTT_COLS;
+    const uint32_t pairs = r1 * (NTT_COLS / 2);
+    for (uint32_t e = threadIdx.x; e < pairs; e += NTT_THREADS) {
+        const uint32_t r = e / (NTT_COLS / 2), cp = (e % (NTT_COLS / 2)) * 2;
+        const ulong2 v = *reinterpret_cast<const ulong2 *>(src + (size_t)r * r2 + c0 + cp);
+        lds[r * NTT_COLS + cp] = v.x;
+        lds[r * NTT_COLS + cp + 1] = v.y;
+    }
+    __syncthreads();
+    const u64 *tw = (INV ? T.itw : T.tw) + (size_t)id * n;
+    const u64 *tw_sh = (INV ? T.itw_sh : T.tw_sh) + (size_t)id * n;
+    lds_stages<INV>(lds, NTT_COLS, (int)T.log_r1, 1, NTT_COLS, true, tw, tw_sh, lc.q, lc.q2,
+                    [](int) { return 1; });
+    u64 sc = 0, sc_sh = 0;
+    if (INV) {
+        sc = scale ? scale[id] : lc.ninv;
+        sc_sh = scale ? scale_sh[id] : lc.ninv_sh;
+    }
+    for (uint32_t e = threadIdx.x; e < pairs; e += NTT_THREADS) {
+        const uint32_t r = e / (NTT_COLS / 2), cp = (e % (NTT_COLS / 2)) * 2;
+        ulong2 v;
+        v.x = lds[r * NTT_COLS + cp];
+        v.y = lds[r * NTT_COLS + cp + 1];
+        if (INV) {  // last pass of the inverse: scale by N^-1 (x folded constant), canonical
+            v.x = shoup_mul(v.x, sc, sc_sh, lc.q);
+            v.y = shoup_mul(v.y, sc, sc_sh, lc.q);
+        }
+        *reinterpret_cast<ulong2 *>(dst + (size_t)r * r2 + c0 + cp) = v;
+    }
+}
+
+template <bool INV>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_row(NttIo io, NttTables T) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const uint32_t poly = blockIdx.y / io.nslots, s = blockIdx.y % io.nslots;
+    const uint32_t id = limb_id_of(io.vslot0 + s, io.nl, T.L);
+    const LimbConst lc = T.limb[id];
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1, r2 = 1u << T.log_r2;
+    const uint32_t tile = n < (uint32_t)NTT_TILE ? n : (uint32_t)NTT_TILE;
+    const uint32_t rows = tile >> T.log_r2, row0 = blockIdx.x * rows;
+    const u64 *src = io.in + (size_t)poly * io.in_stride + (size_t)(io.in_slot0 + s) * n + (size_t)row0 * r2;
+    u64 *dst = io.out + (size_t)poly * io.out_stride + (size_t)(io.out_slot0 + s) * n + (size_t)row0 * r2;
+    for (uint32_t e = threadIdx.x; e < tile / 2; e += NTT_THREADS) {
+        const ulong2 v = reinterpret_cast<const ulong2 *>(src)[e];
+        lds[2 * e] = v.x;
+        lds[2 * e + 1] = v.y;
+    }
+    __syncthreads();
+    const u64 *tw = (INV ? T.itw : T.tw) + (size_t)id * n;
+    const u64 *tw_sh = (INV ? T.itw_sh : T.tw_sh) + (size_t)id * n;
+    const int base0 = (int)(r1 + row0);
+    lds_stages<INV>(lds, (int)rows, (int)T.log_r2, (int)r2, 1, false, tw, tw_sh, lc.q, lc.q2,
+                    [base0](int g) { return base0 + g; });
+    for (uint32_t e = threadIdx.x; e < tile / 2; e += NTT_THREADS) {
+        ulong2 v;
+        v.x = lds[2 * e];
+        v.y = lds[2 * e + 1];
+        if (!INV) {  // last pass of the forward transform: [0,4q) -> [0,q)
+            v.x = v.x >= lc.q2 ? v.x - lc.q2 : v.x;
+            v.x = v.x >= lc.q ? v.x - lc.q : v.x;
+            v.y = v.y >= lc.q2 ? v.y - lc.q2 : v.y;
+            v.y = v.y >= lc.q ? v.y - lc.q : v.y;
+        }
+        reinterpret_cast<ulong2 *>(dst)[e] = v;
+    }
+}
+
+// =====================================================================================
+// coefficient-wise kernels.  grid = (N / (2*256), slots, items); one modulus per block.
+// =====================================================================================
+
+constexpr int EW_THREADS = 256;
+
+struct EwGeom {
+    uint32_t n, nl, L;
+};
+
+#define EW_PROLOGUE(nslots_)                                                   \
+    const uint32_t slot = blockIdx.y, item = blockIdx.z;                       \
+    const uint32_t idx = (blockIdx.x * EW_THREADS + threadIdx.x) * 2;          \
+    if (idx >= g.n) return;                                                    \
+    (void)slot; (void)item;
+
+__device__ __forceinline__ ulong2 ld2(const u64 *p) { return *reinterpret_cast<const ulong2 *>(p); }
+__device__ __forceinline__ void st2(u64 *p, ulong2 v) { *reinterpret_cast<ulong2 *>(p) = v; }
+
+// out = a + b over [items][slots][N]   (EvalAddCore)
+__global__ void k_add(const u64 *a, const u64 *b, u64 *out, EwGeom g, const LimbConst *limb, uint32_t slots) {
+    EW_PROLOGUE(slots)
+    const u64 q = limb[limb_id_of(slot % g.nl, g.nl, g.L)].q;
+    const size_t off = ((size_t)item * slots + slot) * g.n + idx;
+    ulong2 x = ld2(a + off), y = ld2(b + off);
+    x.x = add_mod(x.x, y.x, q);
+    x.y = add_mod(x.y, y.y, q);
+    st2(out + off, x);
+}
+
+// out[item][slot] = sum_k in[k][item][slot]  (n-ary EvalAdd; lazy u64 sum of < 2^61 terms, one reduction)
+__global__ void k_sum(const u64 *in, u64 *out, EwGeom g, const LimbConst *limb, uint32_t slots,
+                      uint32_t n_clients, size_t client_stride) {
+    EW_PROLOGUE(slots)
+    const LimbConst lc = limb[limb_id_of(slot % g.nl, g.nl, g.L)];
+    const size_t off = ((size_t)item * slots + slot) * g.n + idx;
+    u64 s0 = 0, s1 = 0;
+    uint32_t pending = 0;
+    for (uint32_t k = 0; k < n_clients; ++k) {
+        const ulong2 v = ld2(in + (size_t)k * client_stride + off);
+        s0 += v.x;
+        s1 += v.y;
+        if (++pending == 4) {  // 4 canonical terms + 1 reduced carry < 5 * 2^61 < 2^64
+            s0 = reduce_word(s0, lc);
+            s1 = reduce_word(s1, lc);
+            pending = 1;
+        }
+    }
+    ulong2 r;
+    r.x = reduce_word(s0, lc);
+    r.y = reduce_word(s1, lc);
+    st2(out + off, r);
+}
+
+// in-place word-wise reduction after an integer-sum collective
+__global__ void k_reduce(u64 *ct, EwGeom g, const LimbConst *limb, uint32_t slots) {
+    EW_PROLOGUE(slots)
+    const LimbConst lc = limb[limb_id_of(slot % g.nl, g.nl, g.L)];
+    const size_t off = ((size_t)item * slots + slot) * g.n + idx;
+    ulong2 v = ld2(ct + off);
+    v.x = reduce_word(v.x, lc);
+    v.y = reduce_word(v.y, lc);
+    st2(ct + off, v);
+}
+
+// ct[item][slot] *= f[slot % nl]   (EvalMultCoreInPlace with a per-limb integer constant)
+__global__ void k_mul_const(u64 *ct, EwGeom g, const LimbConst *limb, uint32_t slots, const u64 *f,
+                            const u64 *f_sh) {
+    EW_PROLOGUE(slots)
+    const uint32_t l = slot % g.nl;
+    const u64 q = limb[limb_id_of(l, g.nl, g.L)].q;
+    const size_t off = ((size_t)item * slots + slot) * g.n + idx;
+    ulong2 v = ld2(ct + off);
+    v.x = shoup_mul(v.x, f[l], f_sh[l], q);
+    v.y = shoup_mul(v.y, f[l], f_sh[l], q);
+    st2(ct + off, v);
+}
+
+// NativeVectorT::SwitchModulus of the dropped limb (COEFFICIENT format) into limb `slot`:
+// centred lift, v > floor(q_last/2) is negative.  last: [items][N]; out: [items][nl-1][N]
+__global__ void k_switch_modulus(const u64 *last, u64 *out, EwGeom g, const LimbConst *limb, u64 q_last) {
+    EW_PROLOGUE(g.nl - 1)
+    const LimbConst lc = limb[slot];
+    const u64 half = q_last >> 1;
+    const u64 ql_mod = reduce_word(q_last, lc);
+    const ulong2 v = ld2(last + (size_t)item * g.n + idx);
+    ulong2 r;
+    u64 a = reduce_word(v.x, lc);
+    r.x = v.x > half ? sub_mod(a, ql_mod, lc.q) : a;
+    a = reduce_word(v.y, lc);
+    r.y = v.y > half ? sub_mod(a, ql_mod, lc.q) : a;
+    st2(out + ((size_t)item * (g.nl - 1) + slot) * g.n + idx, r);
+}
+
+// DropLastElementAndScale tail: out[item][i] = (in[item][i] - tmp[item][i]) * c[i],
+// c = q_last^-1 (times the EvalMult constant when the two are fused).  in has nl slots, out nl-1.
+__global__ void k_sub_mul(const u64 *in, const u64 *tmp, u64 *out, EwGeom g, const LimbConst *limb,
+                          const u64 *c, const u64 *c_sh) {
+    EW_PROLOGUE(g.nl - 1)
+    const u64 q = limb[slot].q;
+    const ulong2 x = ld2(in + ((size_t)item * g.nl + slot) * g.n + idx);
+    const size_t off = ((size_t)item * (g.nl - 1) + slot) * g.n + idx;
+    const ulong2 t = ld2(tmp + off);
+    ulong2 r;
+    r.x = shoup_mul(sub_mod(x.x, t.x, q), c[slot], c_sh[slot], q);
+    r.y = shoup_mul(sub_mod(x.y, t.y, q), c[slot], c_sh[slot], q);
+    st2(out + off, r);
+}
+
+// ApproxModDown tail: out[item][i] = (in[item][i] - conv[item][i]) * Pinv[i] (+ add[item/2][i] on even items).
+// in has ext = nl+K slots per item, conv/out have nl.
+__global__ void k_moddown_tail(const u64 *in, const u64 *conv, u64 *out, EwGeom g, const LimbConst *limb,
+                               uint32_t ext, const u64 *pinv, const u64 *pinv_sh, const u64 *add,
+                               size_t add_stride, size_t out_item_stride) {
+    EW_PROLOGUE(g.nl)
+    const u64 q = limb[slot].q;
+    const ulong2 x = ld2(in + ((size_t)item * ext + slot) * g.n + idx);
+    const ulong2 t = ld2(conv + ((size_t)item * g.nl + slot) * g.n + idx);
+    ulong2 r;
+    r.x = shoup_mul(sub_mod(x.x, t.x, q), pinv[slot], pinv_sh[slot], q);
+    r.y = shoup_mul(sub_mod(x.y, t.y, q), pinv[slot], pinv_sh[slot], q);
+    if (add && (item & 1) == 0) {
+        const ulong2 c = ld2(add + (size_t)(item >> 1) * add_stride + (size_t)slot * g.n + idx);
+        r.x = add_mod(r.x, c.x, q);
+        r.y = add_mod(r.y, c.y, q);
+    }
+    st2(out + (size_t)item * out_item_stride + (size_t)slot * g.n + idx, r);
+}
+
+// copy selected limb slots between strided polynomial arrays
+__global__ void k_copy_slots(const u64 *in, size_t in_stride, uint32_t in_slot0, u64 *out, size_t out_stride,
+                             uint32_t out_slot0, uint32_t n) {
+    const uint32_t slot = blockIdx.y, item = blockIdx.z;
+    const uint32_t idx = (blockIdx.x * EW_THREADS + threadIdx.x) * 2;
+    if (idx >= n) return;
+    st2(out + (size_t)item * out_stride + (size_t)(out_slot0 + slot) * n + idx,
+        ld2(in + (size_t)item * in_stride + (size_t)(in_slot0 + slot) * n + idx));
+}
+
+// =====================================================================================
+// hybrid key switching kernels
+// =====================================================================================
+
+// ApproxSwitchCRTBasis: one thread per coefficient.  in: [items][*][N] COEFFICIENT, canonical.
+template <int N_IN>
+__global__ void k_baseconv(const u64 *in, size_t in_stride, u64 *out, size_t out_stride, DevConv cv,
+                           const LimbConst *limb, uint32_t n) {
+    const uint32_t idx = blockIdx.x * EW_THREADS + threadIdx.x;
+    const uint32_t item = blockIdx.y;
+    if (idx >= n) return;
+    u64 t[N_IN];
+#pragma unroll
+    for (int i = 0; i < N_IN; ++i) {
+        const u64 x = in[(size_t)item * in_stride + (size_t)cv.src_slot[i] * n + idx];
+        t[i] = shoup_mul(x, cv.hatinv[i], cv.hatinv_sh[i], limb[cv.src_id[i]].q);
+    }
+    for (uint32_t j = 0; j < cv.n_out; ++j) {
+        u64 hi = 0, lo = 0;
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i) mac128(hi, lo, t[i], cv.hat[i * cv.n_out + j]);
+        out[(size_t)item * out_stride + (size_t)cv.dst_slot[j] * n + idx] = reduce_wide(hi, lo, limb[cv.dst_id[j]]);
+    }
+}
+
+// EvalFastKeySwitchCoreExt: ctilde[item][k][slot] = sum_j digits[item][j][slot] * evk[j][k][id(slot)]
+__global__ void k_inner_product(const u64 *digits, const u64 *evk, u64 *ctilde, EwGeom g, const LimbConst *limb,
+                                uint32_t ext, uint32_t nparts, uint32_t D) {
+    EW_PROLOGUE(ext)
+    const uint32_t id = limb_id_of(slot, g.nl, g.L);
+    const LimbConst lc = limb[id];
+    u64 h0x = 0, l0x = 0, h0y = 0, l0y = 0, h1x = 0, l1x = 0, h1y = 0, l1y = 0;
+    for (uint32_t j = 0; j < nparts; ++j) {
+        const ulong2 d = ld2(digits + (((size_t)item * nparts + j) * ext + slot) * g.n + idx);
+        const ulong2 b = ld2(evk + (((size_t)j * 2 + 0) * D + id) * g.n + idx);
+        const ulong2 a = ld2(evk + (((size_t)j * 2 + 1) * D + id) * g.n + idx);
+        mac128(h0x, l0x, d.x, b.x);
+        mac128(h0y, l0y, d.y, b.y);
+        mac128(h1x, l1x, d.x, a.x);
+        mac128(h1y, l1y, d.y, a.y);
+    }
+    ulong2 r0, r1;
+    r0.x = reduce_wide(h0x, l0x, lc);
+    r0.y = reduce_wide(h0y, l0y, lc);
+    r1.x = reduce_wide(h1x, l1x, lc);
+    r1.y = reduce_wide(h1y, l1y, lc);
+    st2(ctilde + (((size_t)item * 2 + 0) * ext + slot) * g.n + idx, r0);
+    st2(ctilde + (((size_t)item * 2 + 1) * ext + slot) * g.n + idx, r1);
+}
+
+// =====================================================================================
+// key generation / encryption / decryption kernels
+// =====================================================================================
+
+__device__ __forceinline__ u64 lift_value(int8_t v, const LimbConst &lc) {
+    return v == 0 ? 0 : (v > 0 ? 1 : lc.q - 1);
+}
+__device__ __forceinline__ u64 lift_value(int32_t v, const LimbConst &lc) {
+    const u64 m = reduce_word((u64)(v < 0 ? -(int64_t)v : (int64_t)v), lc);
+    return (v < 0 && m != 0) ? lc.q - m : m;
+}
+// exact residue of round(x) for a double x (|x| < 2^120): mantissa * 2^e reduced in 128 bits
+__device__ __forceinline__ u64 lift_value(double x, const LimbConst &lc) {
+    const double r = round(x);
+    const bool neg = r < 0;
+    const double a = fabs(r);
+    u64 m;
+    if (a < 9223372036854775808.0) {
+        m = reduce_word((u64)a, lc);
+    } else {
+        int e;
+        const double f = frexp(a, &e);                 // a = f * 2^e, f in [0.5,1)
+        const u64 mant = (u64)ldexp(f, 53);            // 53-bit integer mantissa
+        const int sh = e - 53;                         // a = mant * 2^sh, 11 <= sh <= 67
+        const u64 hi = sh >= 64 ? (mant << (sh - 64)) : (mant >> (64 - sh));
+        const u64 lo = sh >= 64 ? 0 : (mant << sh);
+        m = reduce_wide(hi, lo, lc);
+    }
+    return (neg && m != 0) ? lc.q - m : m;
+}
+
+// signed coefficient vectors -> residues: coef [items][N] -> out [items][ext][N]
+template <typename T>
+__global__ void k_lift(const T *coef, u64 *out, EwGeom g, const LimbConst *limb, uint32_t ext) {
+    EW_PROLOGUE(ext)
+    const LimbConst lc = limb[limb_id_of(slot, g.nl, g.L)];
+    const T *c = coef + (size_t)item * g.n + idx;
+    ulong2 r;
+    r.x = lift_value(c[0], lc);
+    r.y = lift_value(c[1], lc);
+    st2(out + ((size_t)item * ext + slot) * g.n + idx, r);
+}
+
+// out = x*y + z (+ w*wc) over limb ids; every operand addressed by (base, item stride, slot->offset rule)
+struct Opnd {
+    const u64 *p;
+    size_t item_stride;  // words between items (0 = broadcast)
+    uint32_t by_id;      // 1: limb offset = limb id * N (keys over QP); 0: offset = slot * N
+};
+__device__ __forceinline__ ulong2 ld_op(const Opnd &o, uint32_t item, uint32_t slot, uint32_t id, uint32_t n,
+                                        uint32_t idx) {
+    return ld2(o.p + (size_t)item * o.item_stride + (size_t)(o.by_id ? id : slot) * n + idx);
+}
+__global__ void k_fma(Opnd x, Opnd y, Opnd z, Opnd w, const u64 *wc, int negate_xy, u64 *out,
+                      size_t out_item_stride, uint32_t out_by_id, EwGeom g, const LimbConst *limb, uint32_t slots) {
+    EW_PROLOGUE(slots)
+    const uint32_t id = limb_id_of(slot, g.nl, g.L);
+    const LimbConst lc = limb[id];
+    const ulong2 a = ld_op(x, item, slot, id, g.n, idx), b = ld_op(y, item, slot, id, g.n, idx);
+    ulong2 r;
+    r.x = mul_mod(a.x, b.x, lc);
+    r.y = mul_mod(a.y, b.y, lc);
+    if (negate_xy) {
+        r.x = r.x ? lc.q - r.x : 0;
+        r.y = r.y ? lc.q - r.y : 0;
+    }
+    if (z.p) {
+        const ulong2 c = ld_op(z, item, slot, id, g.n, idx);
+        r.x = add_mod(r.x, c.x, lc.q);
+        r.y = add_mod(r.y, c.y, lc.q);
+    }
+    if (w.p) {
+        const ulong2 d = ld_op(w, item, slot, id, g.n, idx);
+        const u64 k = wc ? wc[id] : 1;
+        r.x = add_mod(r.x, wc ? mul_mod(d.x, k, lc) : d.x, lc.q);
+        r.y = add_mod(r.y, wc ? mul_mod(d.y, k, lc) : d.y, lc.q);
+    }
+    st2(out + (size_t)item * out_item_stride + (size_t)(out_by_id ? id : slot) * g.n + idx, r);
+}
+
+// =====================================================================================
+// Engine
+// =====================================================================================
+
+static dim3 ew_grid(uint32_t n, uint32_t slots, uint32_t items) {
+    return dim3((n / 2 + EW_THREADS - 1) / EW_THREADS, slots, items);
+}
+
+Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
+    if (const char *e = std::getenv("MKCKKS_CHUNK")) {
+        int v = std::atoi(e);
+        if (v >= 1 && v <= 64) chunk_ = (uint32_t)v;
+    }
+    if (device_ < 0) return;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= device_)
+        throw NoDevice("no HIP device " + std::to_string(device_) + " (found " + std::to_string(count) + ")");
+    MK_HIP(hipSetDevice(device_));
+    const uint32_t D = ps_.D, n = ps_.n;
+    MK_HIP(hipMalloc(&d_limb_, D * sizeof(LimbConst)));
+    MK_HIP(hipMemcpy(d_limb_, ps_.limb.data(), D * sizeof(LimbConst), hipMemcpyHostToDevice));
+    const size_t tbytes = (size_t)D * n * sizeof(u64);
+    MK_HIP(hipMalloc(&d_tw_, tbytes));
+    MK_HIP(hipMalloc(&d_tw_sh_, tbytes));
+    MK_HIP(hipMalloc(&d_itw_, tbytes));
+    MK_HIP(hipMalloc(&d_itw_sh_, tbytes));
+    std::vector<u64> w, wsh;
+    for (uint32_t i = 0; i < D; ++i) {
+        ps_.twiddles(i, false, w, wsh);
+        MK_HIP(hipMemcpy(d_tw_ + (size_t)i * n, w.data(), n * sizeof(u64), hipMemcpyHostToDevice));
+        MK_HIP(hipMemcpy(d_tw_sh_ + (size_t)i * n, wsh.data(), n * sizeof(u64), hipMemcpyHostToDevice));
+        ps_.twiddles(i, true, w, wsh);
+        MK_HIP(hipMemcpy(d_itw_ + (size_t)i * n, w.data(), n * sizeof(u64), hipMemcpyHostToDevice));
+        MK_HIP(hipMemcpy(d_itw_sh_ + (size_t)i * n, wsh.data(), n * sizeof(u64), hipMemcpyHostToDevice));
+    }
+    tabs_.limb = d_limb_;
+    tabs_.tw = d_tw_; tabs_.tw_sh = d_tw_sh_; tabs_.itw = d_itw_; tabs_.itw_sh = d_itw_sh_;
+    tabs_.log_n = ps_.log_n;
+    tabs_.log_r1 = ps_.log_n / 2;
+    tabs_.log_r2 = ps_.log_n - tabs_.log_r1;
+    tabs_.L = ps_.L;
+}
+
+Engine::~Engine() {
+    if (device_ < 0) return;
+    (void)hipSetDevice(device_);
+    (void)hipDeviceSynchronize();
+    for (void *p : {(void *)d_limb_, (void *)d_tw_, (void *)d_tw_sh_, (void *)d_itw_, (void *)d_itw_sh_, (void *)ws_})
+        if (p) (void)hipFree(p);
+    for (void *p : owned_) (void)hipFree(p);
+}
+
+void Engine::sync() {
+    need_device();
+    MK_HIP(hipStreamSynchronize(stream_));
+}
+void *Engine::dev_alloc(size_t bytes) {
+    need_device();
+    void *p = nullptr;
+    MK_HIP(hipMalloc(&p, bytes ? bytes : 8));
+    return p;
+}
+void Engine::dev_free(void *p) {
+    need_device();
+    MK_HIP(hipStreamSynchronize(stream_));
+    MK_HIP(hipFree(p));
+}
+void Engine::upload(void *d, const void *h, size_t bytes) {
+    need_device();
+    MK_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream_));
+    MK_HIP(hipStreamSynchronize(stream_));
+}
+void Engine::download(void *h, const void *d, size_t bytes) {
+    need_device();
+    MK_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream_));
+    MK_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::check_nl(uint32_t nl) const {
+    if (nl < 1 || nl > ps_.L) throw std::invalid_argument("nl out of range");
+}
+
+u64 *Engine::workspace(size_t words) {
+    if (words > ws_words_) {
+        MK_HIP(hipStreamSynchronize(stream_));
+        if (ws_) MK_HIP(hipFree(ws_));
+        ws_ = nullptr;
+        ws_words_ = 0;
+        MK_HIP(hipMalloc(&ws_, words * sizeof(u64)));
+        ws_words_ = words;
+    }
+    return ws_;
+}
+
+const u64 *Engine::limb_vector(const std::string &key, const std::vector<u64> &vals) {
+    auto it = vec_cache_.find(key);
+    if (it != vec_cache_.end()) return it->second;
+    u64 *d = nullptr;
+    MK_HIP(hipMalloc(&d, vals.size() * sizeof(u64)));
+    MK_HIP(hipMemcpy(d, vals.data(), vals.size() * sizeof(u64), hipMemcpyHostToDevice));
+    owned_.push_back(d);
+    vec_cache_[key] = d;
+    return d;
+}
+
+static DevConv to_dev(const BaseConvTable &t, const u64 *d_hat) {
+    if (t.src.size() > (size_t)MAX_CONV_IN || t.dst.size() > (size_t)MAX_CONV_OUT)
+        throw std::invalid_argument("base conversion larger than supported");
+    DevConv c{};
+    c.n_in = (uint32_t)t.src.size();
+    c.n_out = (uint32_t)t.dst.size();
+    for (size_t i = 0; i < t.src.size(); ++i) {
+        c.src_id[i] = t.src[i];
+        c.hatinv[i] = t.hatinv[i];
+        c.hatinv_sh[i] = t.hatinv_sh[i];
+    }
+    for (size_t j = 0; j < t.dst.size(); ++j) c.dst_id[j] = t.dst[j];
+    c.hat = d_hat;
+    return c;
+}
+
+const DevConv &Engine::modup_conv(uint32_t nl, uint32_t part) {
+    auto key = std::make_pair(nl, part);
+    auto it = modup_cache_.find(key);
+    if (it != modup_cache_.end()) return it->second;
+    BaseConvTable t = ps_.modup_table(nl, part);
+    const u64 *d_hat = limb_vector("modup_hat_" + std::to_string(nl) + "_" + std::to_string(part), t.hat);
+    DevConv c = to_dev(t, d_hat);
+    const uint32_t lo = part * ps_.alpha;
+    for (uint32_t i = 0; i < c.n_in; ++i) c.src_slot[i] = lo + i;  // slot inside the nl-limb input polynomial
+    // targets: all slots of the extended polynomial except the digit's own
+    uint32_t w = 0;
+    for (uint32_t s = 0; s < nl + ps_.K; ++s)
+        if (s < lo || s >= lo + c.n_in) c.dst_slot[w++] = s;
+    return modup_cache_.emplace(key, c).first->second;
+}
+
+const DevConv &Engine::moddown_conv(uint32_t nl) {
+    auto it = moddown_cache_.find(nl);
+    if (it != moddown_cache_.end()) return it->second;
+    BaseConvTable t = ps_.moddown_table(nl);
+    const u64 *d_hat = limb_vector("moddown_hat_" + std::to_string(nl), t.hat);
+    DevConv c = to_dev(t, d_hat);
+    for (uint32_t k = 0; k < c.n_in; ++k) c.src_slot[k] = k;
+    for (uint32_t i = 0; i < c.n_out; ++i) c.dst_slot[i] = i;
+    return moddown_cache_.emplace(nl, c).first->second;
+}
+
+template <int N_IN>
+static void launch_baseconv_n(const u64 *in, size_t in_stride, u64 *out, size_t out_stride, const DevConv &cv,
+                              const LimbConst *limb, uint32_t n, uint32_t items, hipStream_t s) {
+    dim3 grid((n + EW_THREADS - 1) / EW_THREADS, items);
+    k_baseconv<N_IN><<<grid, EW_THREADS, 0, s>>>(in, in_stride, out, out_stride, cv, limb, n);
+}
+static void launch_baseconv(const u64 *in, size_t in_stride, u64 *out, size_t out_stride, const DevConv &cv,
+                            const LimbConst *limb, uint32_t n, uint32_t items, hipStream_t s) {
+    switch (cv.n_in) {
+        case 1: launch_baseconv_n<1>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
+        case 2: launch_baseconv_n<2>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
+        case 3: launch_baseconv_n<3>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
+        case 4: launch_baseconv_n<4>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
+        case 5: launch_baseconv_n<5>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
+        case 6: launch_baseconv_n<6>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
+        case 7: launch_baseconv_n<7>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
+        case 8: launch_baseconv_n<8>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
+        default: throw std::invalid_argument("base conversion fan-in unsupported");
+    }
+    MK_HIP(hipGetLastError());
+}
+
+// ---- transforms ---------------------------------------------------------------------
+
+// generic two-pass launcher: reads `io.in`, leaves the result in `io.out` (may be the same buffer)
+static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inverse, const u64 *scale,
+                       const u64 *scale_sh, hipStream_t s) {
+    if (n_polys == 0 || io.nslots == 0) return;
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1, r2 = 1u << T.log_r2;
+    const uint32_t tile = n < (uint32_t)NTT_TILE ? n : (uint32_t)NTT_TILE;
+    const dim3 gcol(r2 / NTT_COLS, n_polys * io.nslots), grow(n / tile, n_polys * io.nslots);
+    const size_t lds_col = (size_t)r1 * NTT_COLS * sizeof(u64), lds_row = (size_t)tile * sizeof(u64);
+    NttIo second = io;  // second pass runs in place on the output
+    second.in = io.out;
+    second.in_stride = io.out_stride;
+    second.in_slot0 = io.out_slot0;
+    if (!inverse) {
+        k_ntt_col<false><<<gcol, NTT_THREADS, lds_col, s>>>(io, T, nullptr, nullptr);
+        k_ntt_row<false><<<grow, NTT_THREADS, lds_row, s>>>(second, T);
+    } else {
+        k_ntt_row<true><<<grow, NTT_THREADS, lds_row, s>>>(io, T);
+        k_ntt_col<true><<<gcol, NTT_THREADS, lds_col, s>>>(second, T, scale, scale_sh);
+    }
+    MK_HIP(hipGetLastError());
+}
+
+void Engine::ntt_launch(u64 *d, uint32_t n_polys, uint32_t nl, uint32_t ext, bool inverse, const u64 *scale,
+                        const u64 *scale_sh) {
+    NttIo io{d, d, (size_t)ext * ps_.n, (size_t)ext * ps_.n, 0, 0, 0, ext, nl};
+    ntt_passes(io, tabs_, n_polys, inverse, scale, scale_sh, stream_);
+}
+
+void Engine::ntt_forward(u64 *d, uint32_t n_polys, uint32_t nl, bool with_p) {
+    need_device();
+    if (nl > ps_.L || (nl == 0 && !with_p)) throw std::invalid_argument("nl out of range");
+    ntt_launch(d, n_polys, nl, nl + (with_p ? ps_.K : 0), false, nullptr, nullptr);
+}
+void Engine::ntt_inverse(u64 *d, uint32_t n_polys, uint32_t nl, bool with_p) {
+    need_device();
+    if (nl > ps_.L || (nl == 0 && !with_p)) throw std::invalid_argument("nl out of range");
+    ntt_launch(d, n_polys, nl, nl + (with_p ? ps_.K : 0), true, nullptr, nullptr);
+}
+
+// ---- aggregation --------------------------------------------------------------------
+
+void Engine::eval_add(const u64 *a, const u64 *b, u64 *out, uint32_t n_ct, uint32_t nl) {
+    need_device();
+    check_nl(nl);
+    if (!n_ct) return;
+    EwGeom g{ps_.n, nl, ps_.L};
+    k_add<<<ew_grid(ps_.n, 2 * nl, n_ct), EW_THREADS, 0, stream_>>>(a, b, out, g, d_limb_, 2 * nl);
+    MK_HIP(hipGetLastError());
+}
+
+void Engine::eval_sum(const u64 *in, u64 *out, uint32_t n_clients, uint32_t n_ct, uint32_t nl) {
+    need_device();
+    check_nl(nl);
+    if (!n_ct || !n_clients) return;
+    EwGeom g{ps_.n, nl, ps_.L};
+    k_sum<<<ew_grid(ps_.n, 2 * nl, n_ct), EW_THREADS, 0, stream_>>>(in, out, g, d_limb_, 2 * nl, n_clients,
+                                                                 (size_t)n_ct * 2 * nl * ps_.n);
+    MK_HIP(hipGetLastError());
+}
+
+void Engine::reduce_mod(u64 *ct, uint32_t n_ct, uint32_t nl, uint32_t n_terms) {
+    need_device();
+    check_nl(nl);
+    if (n_terms > 8) throw std::invalid_argument("integer-sum collective supports at most 8 terms (q < 2^61)");
+    if (!n_ct) return;
+    EwGeom g{ps_.n, nl, ps_.L};
+    k_reduce<<<ew_grid(ps_.n, 2 * nl, n_ct), EW_THREADS, 0, stream_>>>(ct, g, d_limb_, 2 * nl);
+    MK_HIP(hipGetLastError());
+}
+
+void Engine::mult_const(u64 *ct, uint32_t n_ct, uint32_t nl, const std::vector<u64> &factors) {
+    need_device();
+    check_nl(nl);
+    if (!n_ct) return;
+    std::vector<u64> both(factors);
+    for (uint32_t i = 0; i < nl; ++i) both.push_back(h_shoup(factors[i], ps_.moduli[i]));
+    u64 *d_f = workspace(2 * nl);
+    MK_HIP(hipMemcpyAsync(d_f, both.data(), both.size() * sizeof(u64), hipMemcpyHostToDevice, stream_));
+    MK_HIP(hipStreamSynchronize(stream_));  // `both` is a stack-local staging buffer
+    EwGeom g{ps_.n, nl, ps_.L};
+    k_mul_const<<<ew_grid(ps_.n, 2 * nl, n_ct), EW_THREADS, 0, stream_>>>(ct, g, d_limb_, 2 * nl, d_f, d_f + nl);
+    MK_HIP(hipGetLastError());
+}
+
+void Engine::rescale(const u64 *in, u64 *out, uint32_t n_ct, uint32_t nl, const std::vector<u64> *factors) {
+    need_device();
+    check_nl(nl);
+    if (nl < 2) throw std::invalid_argument("rescale needs at least 2 limbs");
+    if (!n_ct) return;
+    const uint32_t n = ps_.n, last = nl - 1, items = 2 * n_ct;
+    // constants c_i = q_last^-1 (* EvalMult constant) mod q_i
+    std::vector<u64> c(2 * last);
+    for (uint32_t i = 0; i < last; ++i) {
+        u64 v = ps_.q_inv_mod(last, i);
+        if (factors) v = h_mulmod(v, (*factors)[i], ps_.moduli[i]);
+        c[i] = v;
+        c[last + i] = h_shoup(v, ps_.moduli[i]);
+    }
+    const size_t w_last = (size_t)items * n, w_tmp = (size_t)items * last * n;
+    u64 *ws = workspace(w_last + w_tmp + 2 * last);
+    u64 *d_last = ws, *d_tmp = ws + w_last, *d_c = d_tmp + w_tmp;
+    MK_HIP(hipMemcpyAsync(d_c, c.data(), c.size() * sizeof(u64), hipMemcpyHostToDevice, stream_));
+    MK_HIP(hipStreamSynchronize(stream_));
+    // 1. dropped limb -> COEFFICIENT format
+    NttIo io{in, d_last, (size_t)nl * n, (size_t)n, last, 0, last, 1, nl};
+    ntt_passes(io, tabs_, items, true, nullptr, nullptr, stream_);
+    // 2. centred switch of modulus into every remaining limb, 3. back to EVALUATION
+    EwGeom g{n, nl, ps_.L};
+    k_switch_modulus<<<ew_grid(n, last, items), EW_THREADS, 0, stream_>>>(d_last, d_tmp, g, d_limb_, ps_.moduli[last]);
+    MK_HIP(hipGetLastError());
+    ntt_launch(d_tmp, items, last, last, false, nullptr, nullptr);
+    // 4. (c_i - tmp_i) * q_last^-1 [* constant]
+    k_sub_mul<<<ew_grid(n, last, items), EW_THREADS, 0, stream_>>>(in, d_tmp, out, g, d_limb_, d_c, d_c + last);
+    MK_HIP(hipGetLastError());
+}
+
+// ---- hybrid key switching -----------------------------------------------------------
+
+void Engine::modup(const u64 *c1, u64 *digits, uint32_t cnt, uint32_t nl) {
+    need_device();
+    check_nl(nl);
+    if (!cnt) return;
+    const uint32_t n = ps_.n, ext = nl + ps_.K, nparts = ps_.num_parts(nl);
+    // the digit buffers are also the NTT scratch; the coefficient copy of c1 lives in the arena
+    u64 *coef = workspace((size_t)cnt * nl * n);
+    NttIo io{c1, coef, (size_t)nl * n, (size_t)nl * n, 0, 0, 0, nl, nl};
+    ntt_passes(io, tabs_, cnt, true, nullptr, nullptr, stream_);
+    const size_t dstride = (size_t)nparts * ext * n;
+    for (uint32_t part = 0; part < nparts; ++part) {
+        const DevConv &cv = modup_conv(nl, part);
+        const uint32_t lo = part * ps_.alpha, hi = lo + cv.n_in;
+        u64 *dig = digits + (size_t)part * ext * n;
+        launch_baseconv(coef, (size_t)nl * n, dig, dstride, cv, d_limb_, n, cnt, stream_);
+        if (lo > 0) {
+            NttIo a{dig, dig, dstride, dstride, 0, 0, 0, lo, nl};
+            ntt_passes(a, tabs_, cnt, false, nullptr, nullptr, stream_);
+        }
+        if (hi < ext) {
+            NttIo b{dig, dig, dstride, dstride, hi, hi, hi, ext - hi, nl};
+            ntt_passes(b, tabs_, cnt, false, nullptr, nullptr, stream_);
+        }
+        k_copy_slots<<<ew_grid(n, hi - lo, cnt), EW_THREADS, 0, stream_>>>(c1, (size_t)nl * n, lo, dig, dstride, lo, n);
+        MK_HIP(hipGetLastError());
+    }
+}
+
+void Engine::moddown(const u64 *in, u64 *out, uint32_t cnt, uint32_t nl) {
+    need_device();
+    check_nl(nl);
+    if (!cnt) return;
+    const uint32_t n = ps_.n, K = ps_.K, ext = nl + K;
+    const size_t w_pc = (size_t)cnt * K * n, w_conv = (size_t)cnt * nl * n;
+    u64 *ws = workspace(w_pc + w_conv + 2 * nl);
+    u64 *pc = ws, *conv = ws + w_pc;
+    std::vector<u64> pinv(2 * nl);
+    for (uint32_t i = 0; i < nl; ++i) {
+        pinv[i] = ps_.p_inv_mod(i);
+        pinv[nl + i] = h_shoup(pinv[i], ps_.moduli[i]);
+    }
+    const u64 *d_pinv = limb_vector("pinv_" + std::to_string(nl), pinv);
+    NttIo io{in, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
+    ntt_passes(io, tabs_, cnt, true, nullptr, nullptr, stream_);
+    launch_baseconv(pc, (size_t)K * n, conv, (size_t)nl * n, moddown_conv(nl), d_limb_, n, cnt, stream_);
+    ntt_launch(conv, cnt, nl, nl, false, nullptr, nullptr);
+    EwGeom g{n, nl, ps_.L};
+    k_moddown_tail<<<ew_grid(n, nl, cnt), EW_THREADS, 0, stream_>>>(in, conv, out, g, d_limb_, ext, d_pinv,
+                                                                 d_pinv + nl, nullptr, 0, (size_t)nl * n);
+    MK_HIP(hipGetLastError());
+}
+
+void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t cnt, uint32_t nl) {
+    const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, nparts = ps_.num_parts(nl), D = ps_.D;
+    const size_t ct_stride = (size_t)2 * nl * n;
+    const size_t w_coef = (size_t)cnt * nl * n, w_dig = (size_t)cnt * nparts * ext * n;
+    const size_t w_til = (size_t)cnt * 2 * ext * n, w_pc = (size_t)cnt * 2 * K * n, w_conv = (size_t)cnt * 2 * nl * n;
+    u64 *ws = workspace(w_coef + w_dig + w_til + w_pc + w_conv);
+    u64 *coef = ws, *dig = coef + w_coef, *til = dig + w_dig, *pc = til + w_til, *conv = pc + w_pc;
+    std::vector<u64> pinv(2 * nl);
+    for (uint32_t i = 0; i < nl; ++i) {
+        pinv[i] = ps_.p_inv_mod(i);
+        pinv[nl + i] = h_shoup(pinv[i], ps_.moduli[i]);
+    }
+    const u64 *d_pinv = limb_vector("pinv_" + std::to_string(nl), pinv);
+    const u64 *c1 = ct + (size_t)nl * n;  // component 1 of item 0; items are ct_stride apart
+
+    // S1: INTT of c1 (EvalKeySwitchPrecomputeCore: SetFormat(COEFFICIENT))
+    NttIo s1{c1, coef, ct_stride, (size_t)nl * n, 0, 0, 0, nl, nl};
+    ntt_passes(s1, tabs_, cnt, true, nullptr, nullptr, stream_);
+    // S2+S3: per digit ApproxSwitchCRTBasis to the complement basis, NTT, own limbs copied
+    const size_t dstride = (size_t)nparts * ext * n;
+    for (uint32_t part = 0; part < nparts; ++part) {
+        const DevConv &cv = modup_conv(nl, part);
+        const uint32_t lo = part * ps_.alpha, hi = lo + cv.n_in;
+        u64 *d = dig + (size_t)part * ext * n;
+        launch_baseconv(coef, (size_t)nl * n, d, dstride, cv, d_limb_, n, cnt, stream_);
+        if (lo > 0) {
+            NttIo a{d, d, dstride, dstride, 0, 0, 0, lo, nl};
+            ntt_passes(a, tabs_, cnt, false, nullptr, nullptr, stream_);
+        }
+        if (hi < ext) {
+            NttIo b{d, d, dstride, dstride, hi, hi, hi, ext - hi, nl};
+            ntt_passes(b, tabs_, cnt, false, nullptr, nullptr, stream_);
+        }
+        k_copy_slots<<<ew_grid(n, hi - lo, cnt), EW_THREADS, 0, stream_>>>(c1, ct_stride, lo, d, dstride, lo, n);
+        MK_HIP(hipGetLastError());
+    }
+    // S4: inner product with the eval key over Q_l P (EvalFastKeySwitchCoreExt)
+    EwGeom g{n, nl, ps_.L};
+    k_inner_product<<<ew_grid(n, ext, cnt), EW_THREADS, 0, stream_>>>(dig, evk, til, g, d_limb_, ext, nparts, D);
+    MK_HIP(hipGetLastError());
+    // S5: ApproxModDown of both components (2*cnt polynomials of ext limbs), + c0 on component 0
+    NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
+    ntt_passes(s5, tabs_, 2 * cnt, true, nullptr, nullptr, stream_);
+    launch_baseconv(pc, (size_t)K * n, conv, (size_t)nl * n, moddown_conv(nl), d_limb_, n, 2 * cnt, stream_);
+    ntt_launch(conv, 2 * cnt, nl, nl, false, nullptr, nullptr);
+    k_moddown_tail<<<ew_grid(n, nl, 2 * cnt), EW_THREADS, 0, stream_>>>(til, conv, out, g, d_limb_, ext, d_pinv,
+                                                                     d_pinv + nl, ct, ct_stride, (size_t)nl * n);
+    MK_HIP(hipGetLastError());
+}
+
+void Engine::reencrypt(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl) {
+    need_device();
+    check_nl(nl);
+    const size_t ct_stride = (size_t)2 * nl * ps_.n;
+    for (uint32_t done = 0; done < n_ct; done += chunk_) {
+        const uint32_t cnt = n_ct - done < chunk_ ? n_ct - done : chunk_;
+        reencrypt_chunk(ct + done * ct_stride, evk, out + done * ct_stride, cnt, nl);
+    }
+}
+
+// ---- keys / client endpoints --------------------------------------------------------
+
+void Engine::keygen(const int8_t *s, const u64 *a, const int32_t *e, u64 *pk, u64 *sk) {
+    need_device();
+    const uint32_t n = ps_.n, D = ps_.D, L = ps_.L;
+    u64 *ee = workspace((size_t)D * n);
+    EwGeom g{n, L, L};
+    k_lift<int8_t><<<ew_grid(n, D, 1), EW_THREADS, 0, stream_>>>(s, sk, g, d_limb_, D);
+    k_lift<int32_t><<<ew_grid(n, D, 1), EW_THREADS, 0, stream_>>>(e, ee, g, d_limb_, D);
+    MK_HIP(hipGetLastError());
+    ntt_launch(sk, 1, L, D, false, nullptr, nullptr);
+    ntt_launch(ee, 1, L, D, false, nullptr, nullptr);
+    // b = e - a*s ; a copied
+    Opnd x{a, 0, 0}, y{sk, 0, 0}, z{ee, 0, 0}, none{nullptr, 0, 0};
+    k_fma<<<ew_grid(n, D, 1), EW_THREADS, 0, stream_>>>(x, y, z, none, nullptr, 1, pk, 0, 0, g, d_limb_, D);
+    MK_HIP(hipGetLastError());
+    MK_HIP(hipMemcpyAsync(pk + (size_t)D * n, a, (size_t)D * n * sizeof(u64), hipMemcpyDeviceToDevice, stream_));
+}
+
+void Engine::rekeygen(const int8_t *s_old, const u64 *pk_new, const int8_t *u, const int32_t *e0,
+                      const int32_t *e1, u64 *evk) {
+    need_device();
+    const uint32_t n = ps_.n, D = ps_.D, L = ps_.L, beta = ps_.beta;
+    const size_t poly = (size_t)D * n;
+    u64 *ws = workspace(poly * (1 + 3 * (size_t)beta) + D);
+    u64 *se = ws, *ue = se + poly, *e0e = ue + poly * beta, *e1e = e0e + poly * beta, *d_gadget = e1e + poly * beta;
+    EwGeom g{n, L, L};
+    k_lift<int8_t><<<ew_grid(n, D, 1), EW_THREADS, 0, stream_>>>(s_old, se, g, d_limb_, D);
+    k_lift<int8_t><<<ew_grid(n, D, beta), EW_THREADS, 0, stream_>>>(u, ue, g, d_limb_, D);
+    k_lift<int32_t><<<ew_grid(n, D, beta), EW_THREADS, 0, stream_>>>(e0, e0e, g, d_limb_, D);
+    k_lift<int32_t><<<ew_grid(n, D, beta), EW_THREADS, 0, stream_>>>(e1, e1e, g, d_limb_, D);
+    MK_HIP(hipGetLastError());
+    ntt_launch(se, 1, L, D, false, nullptr, nullptr);
+    ntt_launch(ue, 3 * beta, L, D, false, nullptr, nullptr);  // ue, e0e, e1e are contiguous
+    for (uint32_t part = 0; part < beta; ++part) {
+        // gadget P mod q_i on the digit's own limbs, 0 elsewhere (KeySwitchGenInternal)
+        std::vector<u64> gad(D, 0);
+        const uint32_t lo = part * ps_.alpha, hi = std::min(L, lo + ps_.alpha);
+        for (uint32_t i = lo; i < hi; ++i) gad[i] = ps_.p_mod(i);
+        MK_HIP(hipMemcpyAsync(d_gadget, gad.data(), D * sizeof(u64), hipMemcpyHostToDevice, stream_));
+        MK_HIP(hipStreamSynchronize(stream_));
+        Opnd p0{pk_new, 0, 0}, p1{pk_new + poly, 0, 0}, uu{ue + part * poly, 0, 0};
+        Opnd z0{e0e + part * poly, 0, 0}, z1{e1e + part * poly, 0, 0}, w{se, 0, 0}, none{nullptr, 0, 0};
+        k_fma<<<ew_grid(n, D, 1), EW_THREADS, 0, stream_>>>(p0, uu, z0, w, d_gadget, 0, evk + (size_t)(part * 2 + 0) * poly,
+                                                         0, 0, g, d_limb_, D);
+        k_fma<<<ew_grid(n, D, 1), EW_THREADS, 0, stream_>>>(p1, uu, z1, none, nullptr, 0, evk + (size_t)(part * 2 + 1) * poly,
+                                                         0, 0, g, d_limb_, D);
+        MK_HIP(hipGetLastError());
+        MK_HIP(hipStreamSynchronize(stream_));  // d_gadget is rewritten next iteration
+    }
+}
+
+void Engine::lift_ntt(const double *coef, u64 *out, uint32_t cnt, uint32_t nl) {
+    need_device();
+    check_nl(nl);
+    if (!cnt) return;
+    EwGeom g{ps_.n, nl, ps_.L};
+    k_lift<double><<<ew_grid(ps_.n, nl, cnt), EW_THREADS, 0, stream_>>>(coef, out, g, d_limb_, nl);
+    MK_HIP(hipGetLastError());
+    ntt_launch(out, cnt, nl, nl, false, nullptr, nullptr);
+}
+
+void Engine::encrypt(const u64 *pk, const u64 *pt, const int8_t *v, const int32_t *e0, const int32_t *e1, u64 *ct,
+                     uint32_t n_ct, uint32_t nl) {
+    need_device();
+    check_nl(nl);
+    if (!n_ct) return;
+    const uint32_t n = ps_.n, D = ps_.D;
+    const size_t poly = (size_t)nl * n;
+    u64 *ws = workspace(3 * poly * n_ct);
+    u64 *ve = ws, *e0e = ve + poly * n_ct, *e1e = e0e + poly * n_ct;
+    EwGeom g{n, nl, ps_.L};
+    k_lift<int8_t><<<ew_grid(n, nl, n_ct), EW_THREADS, 0, stream_>>>(v, ve, g, d_limb_, nl);
+    k_lift<int32_t><<<ew_grid(n, nl, n_ct), EW_THREADS, 0, stream_>>>(e0, e0e, g, d_limb_, nl);
+    k_lift<int32_t><<<ew_grid(n, nl, n_ct), EW_THREADS, 0, stream_>>>(e1, e1e, g, d_limb_, nl);
+    MK_HIP(hipGetLastError());
+    ntt_launch(ve, 3 * n_ct, nl, nl, false, nullptr, nullptr);
+    // c0 = pk0*v + e0 + m ; c1 = pk1*v + e1   (pk addressed by limb id: first nl of its D limbs)
+    Opnd p0{pk, 0, 1}, p1{pk + (size_t)D * n, 0, 1}, vv{ve, poly, 0};
+    Opnd z0{e0e, poly, 0}, z1{e1e, poly, 0}, m{pt, poly, 0}, none{nullptr, 0, 0};
+    k_fma<<<ew_grid(n, nl, n_ct), EW_THREADS, 0, stream_>>>(p0, vv, z0, m, nullptr, 0, ct, 2 * poly, 0, g, d_limb_, nl);
+    k_fma<<<ew_grid(n, nl, n_ct), EW_THREADS, 0, stream_>>>(p1, vv, z1, none, nullptr, 0, ct + poly, 2 * poly, 0, g,
+                                                         d_limb_, nl);
+    MK_HIP(hipGetLastError());
+}
+
+void Engine::decrypt(const u64 *ct, const u64 *sk, u64 *m, uint32_t n_ct, uint32_t nl) {
+    need_device();
+    check_nl(nl);
+    if (!n_ct) return;
+    const uint32_t n = ps_.n;
+    const size_t poly = (size_t)nl * n;
+    EwGeom g{n, nl, ps_.L};
+    // b = c1*s + c0 in EVALUATION, then COEFFICIENT
+    Opnd c1{ct + poly, 2 * poly, 0}, s{sk, 0, 1}, c0{ct, 2 * poly, 0}, none{nullptr, 0, 0};
+    k_fma<<<ew_grid(n, nl, n_ct), EW_THREADS, 0, stream_>>>(c1, s, c0, none, nullptr, 0, m, poly, 0, g, d_limb_, nl);
+    MK_HIP(hipGetLastError());
+    ntt_launch(m, n_ct, nl, nl, true, nullptr, nullptr);
+}
+
+void Engine::host_twiddles(uint32_t limb, bool inverse, std::vector<u64> &out) const {
+    std::vector<u64> sh;
+    ps_.twiddles(limb, inverse, out, sh);
+}
+
+}  // namespace mk

@@ -1,0 +1,116 @@
+// engine.hpp -- device-resident context + batched operations behind the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "modarith.hpp"
+#include "ntt_kernels.hpp"
+#include "params.hpp"
+
+namespace mk {
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct NoDevice : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define MK_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            throw mk::HipError(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ \
+                               ":" + std::to_string(__LINE__) + ")");                             \
+    } while (0)
+
+constexpr int MAX_CONV_IN = 8;    // alpha, K <= 8
+constexpr int MAX_CONV_OUT = 40;  // complement limbs of one digit
+
+// device image of one BaseConvTable, passed to kernels by value (constant/SGPR space)
+struct DevConv {
+    uint32_t n_in, n_out;
+    uint32_t src_id[MAX_CONV_IN];     // limb ids of the sources
+    uint32_t src_slot[MAX_CONV_IN];   // slot of each source inside the input polynomial
+    uint32_t dst_id[MAX_CONV_OUT];    // limb ids of the targets
+    uint32_t dst_slot[MAX_CONV_OUT];  // slot of each target inside the output polynomial
+    u64 hatinv[MAX_CONV_IN], hatinv_sh[MAX_CONV_IN];
+    const u64 *hat;  // device, [n_in][n_out]
+};
+
+class Engine {
+public:
+    explicit Engine(const ParamSet &ps, int device);
+    ~Engine();
+    Engine(const Engine &) = delete;
+    Engine &operator=(const Engine &) = delete;
+
+    const ParamSet &params() const { return ps_; }
+    bool has_device() const { return device_ >= 0; }
+    void set_stream(hipStream_t s) { stream_ = s; }
+    hipStream_t stream() const { return stream_; }
+    void sync();
+
+    void *dev_alloc(size_t bytes);
+    void dev_free(void *p);
+    void upload(void *d, const void *h, size_t bytes);
+    void download(void *h, const void *d, size_t bytes);
+
+    // transforms, in place on u64[n_polys][ext][N]; ext = nl (+K when with_p)
+    void ntt_forward(u64 *d, uint32_t n_polys, uint32_t nl, bool with_p);
+    void ntt_inverse(u64 *d, uint32_t n_polys, uint32_t nl, bool with_p);
+
+    void eval_add(const u64 *a, const u64 *b, u64 *out, uint32_t n_ct, uint32_t nl);
+    void eval_sum(const u64 *in, u64 *out, uint32_t n_clients, uint32_t n_ct, uint32_t nl);
+    void rescale(const u64 *in, u64 *out, uint32_t n_ct, uint32_t nl, const std::vector<u64> *factors);
+    void mult_const(u64 *ct, uint32_t n_ct, uint32_t nl, const std::vector<u64> &factors);
+    void reduce_mod(u64 *ct, uint32_t n_ct, uint32_t nl, uint32_t n_terms);
+
+    void modup(const u64 *c1, u64 *digits, uint32_t n, uint32_t nl);
+    void moddown(const u64 *in, u64 *out, uint32_t n, uint32_t nl);
+    void reencrypt(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl);
+
+    void keygen(const int8_t *s, const u64 *a, const int32_t *e, u64 *pk, u64 *sk);
+    void rekeygen(const int8_t *s_old, const u64 *pk_new, const int8_t *u, const int32_t *e0,
+                  const int32_t *e1, u64 *evk);
+    void encrypt(const u64 *pk, const u64 *pt, const int8_t *v, const int32_t *e0, const int32_t *e1,
+                 u64 *ct, uint32_t n_ct, uint32_t nl);
+    void lift_ntt(const double *coef, u64 *out, uint32_t n, uint32_t nl);
+    void decrypt(const u64 *ct, const u64 *sk, u64 *m, uint32_t n_ct, uint32_t nl);
+
+    void host_twiddles(uint32_t limb, bool inverse, std::vector<u64> &out) const;
+
+private:
+    void need_device() const {
+        if (device_ < 0) throw NoDevice("host-only context: no device operations");
+    }
+    void check_nl(uint32_t nl) const;
+    u64 *workspace(size_t words);  // grow-only scratch arena (stream-ordered reuse)
+    const DevConv &modup_conv(uint32_t nl, uint32_t part);
+    const DevConv &moddown_conv(uint32_t nl);
+    const u64 *limb_vector(const std::string &key, const std::vector<u64> &vals);  // cached small device arrays
+    void ntt_launch(u64 *d, uint32_t n_polys, uint32_t nl, uint32_t ext, bool inverse, const u64 *scale,
+                    const u64 *scale_sh);
+    void reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl);
+
+    ParamSet ps_;
+    int device_ = -1;
+    hipStream_t stream_ = nullptr;
+    NttTables tabs_{};
+    LimbConst *d_limb_ = nullptr;
+    u64 *d_tw_ = nullptr, *d_tw_sh_ = nullptr, *d_itw_ = nullptr, *d_itw_sh_ = nullptr;
+    u64 *ws_ = nullptr;
+    size_t ws_words_ = 0;
+    uint32_t chunk_ = 4;
+    std::map<std::pair<uint32_t, uint32_t>, DevConv> modup_cache_;
+    std::map<uint32_t, DevConv> moddown_cache_;
+    std::map<std::string, u64 *> vec_cache_;
+    std::vector<void *> owned_;
+};
+
+}  // namespace mk

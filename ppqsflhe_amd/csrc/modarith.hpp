@@ -1,0 +1,116 @@
+// modarith.hpp -- 64-bit modular arithmetic for gfx950 device code (and host mirrors).
+//
+// Stands in for OpenFHE's NativeIntegerT::{ModAddFast, ModSubFast, ModMulFastConst,
+// ModMul} ([upstream] core/include/math/hal/intnat/ubintnat.h), reached from every
+// DCRTPoly operation on the hot path.  Results are canonical
+// residues in [0,q) wherever a value is stored as an output; inside transforms the
+// Harvey lazy ranges [0,2q)/[0,4q) are used (q < 2^62).
+//
+// gfx950 has no 64-bit integer multiplier: a 64x64->128 product is four
+// v_mad_u64_u32; a low-64 product is one v_mad_u64_u32 + two v_mul_lo_u32.  The
+// helpers below are written so hipcc emits exactly those.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MK_HD __host__ __device__ __forceinline__
+#define MK_D __device__ __forceinline__
+#else
+#define MK_HD inline
+#define MK_D inline
+#endif
+
+namespace mk {
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+// per-limb constants kept in a device table (one entry per modulus of QP)
+struct LimbConst {
+    u64 q;        // modulus
+    u64 q2;       // 2q
+    u64 mu;       // floor(2^(62+k) / q), k = bit length of q   (Barrett)
+    u64 c64;      // 2^64 mod q                                  (128-bit fold)
+    u64 ninv;     // N^-1 mod q
+    u64 ninv_sh;  // Shoup companion of ninv
+    uint32_t k;   // bit length of q
+    uint32_t sh;  // k - 2: window shift for Barrett
+};
+
+MK_HD u64 mulhi64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((u128)a * b) >> 64);
+#endif
+}
+
+MK_HD void mul128(u64 a, u64 b, u64 &hi, u64 &lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    lo = a * b;
+    hi = __umul64hi(a, b);
+#else
+    u128 p = (u128)a * b;
+    lo = (u64)p;
+    hi = (u64)(p >> 64);
+#endif
+}
+
+MK_HD u64 add_mod(u64 a, u64 b, u64 q) {
+    u64 s = a + b;
+    return s >= q ? s - q : s;
+}
+MK_HD u64 sub_mod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+
+// Shoup multiplication by a constant w with companion wp = floor(w * 2^64 / q).
+// Valid for ANY 64-bit a; lazy result in [0, 2q).
+MK_HD u64 shoup_lazy(u64 a, u64 w, u64 wp, u64 q) {
+    u64 h = mulhi64(a, wp);
+    return a * w - h * q;
+}
+// canonical result in [0, q)
+MK_HD u64 shoup_mul(u64 a, u64 w, u64 wp, u64 q) {
+    u64 r = shoup_lazy(a, w, wp, q);
+    return r >= q ? r - q : r;
+}
+
+// Barrett reduction of a 128-bit x = hi:lo with x < 2^(k+62) (k = bitlen q) to [0,q).
+// qhat = mulhi64(x >> (k-2), mu), mu = floor(2^(62+k)/q): qhat in {Q-2,Q-1,Q}.
+MK_HD u64 barrett_reduce128(u64 hi, u64 lo, const LimbConst &L) {
+    u64 y = (hi << (64 - L.sh)) | (lo >> L.sh);
+    u64 qh = mulhi64(y, L.mu);
+    u64 r = lo - qh * L.q;
+    r = r >= L.q2 ? r - L.q2 : r;
+    return r >= L.q ? r - L.q : r;
+}
+
+// general a*b mod q for a,b < q (product < q^2 < 2^(2k) <= 2^(k+62))
+MK_HD u64 mul_mod(u64 a, u64 b, const LimbConst &L) {
+    u64 hi, lo;
+    mul128(a, b, hi, lo);
+    return barrett_reduce128(hi, lo, L);
+}
+
+// reduce an arbitrary 128-bit accumulator (< 2^124) mod q: fold the high word with
+// 2^64 mod q first so that the Barrett window fits (x' < 2^(k+60) + 2^64).
+MK_HD u64 reduce_wide(u64 hi, u64 lo, const LimbConst &L) {
+    u64 fh, fl;
+    mul128(hi, L.c64, fh, fl);
+    u64 nlo = fl + lo;
+    u64 nhi = fh + (nlo < fl ? 1 : 0);
+    return barrett_reduce128(nhi, nlo, L);
+}
+
+// reduce one 64-bit word mod q (q may be much smaller than 2^64)
+MK_HD u64 reduce_word(u64 x, const LimbConst &L) { return barrett_reduce128(0, x, L); }
+
+// 128-bit accumulate acc += a*b
+MK_HD void mac128(u64 &hi, u64 &lo, u64 a, u64 b) {
+    u64 ph, pl;
+    mul128(a, b, ph, pl);
+    lo += pl;
+    hi += ph + (lo < pl ? 1 : 0);
+}
+
+}  // namespace mk

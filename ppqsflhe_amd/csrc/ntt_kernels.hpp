@@ -1,0 +1,92 @@
+// ntt_kernels.hpp -- negacyclic NTT / INTT over RNS limbs for gfx950.
+//
+// Stands in for DCRTPolyImpl::SwitchFormat -> ChineseRemainderTransformFTTNat::
+// {ForwardTransformToBitReverse, InverseTransformFromBitReverse} ([upstream]
+// transformnat-impl.h).  Same mathematical map (convention P4:
+// natural-order input, bit-reversed output, psi-power table in bit-reversed order), so
+// outputs are bit-identical; the schedule is MI355X-first:
+//
+//   N = R1 x R2.  A 2^16-point limb (512 KiB) does not fit the 160 KiB LDS of a CU, so
+//   a transform is two launches, each streaming the limb once in coalesced segments:
+//   - column pass: stages 0..log R1-1 couple elements R2 apart.  A workgroup owns a
+//     [R1 rows][16 columns] tile (16 x 8 B = one 128-B segment per row), transforms the
+//     16 columns in LDS; every column uses the same log R1 levels of twiddles.
+//   - row pass: stages log R1..log N-1 act inside contiguous rows of R2 elements.  A
+//     workgroup owns TILE/R2 consecutive rows (contiguous in HBM); row r uses twiddle
+//     index 2^s'(R1 + r) + group at local stage s'.
+//   The inverse (Gentleman-Sande) runs the same two passes in the opposite order with
+//   the inverse table, then scales by N^-1 (optionally times a folded per-limb constant).
+//
+//   Butterflies are Harvey lazy: forward keeps values in [0,4q), inverse in [0,2q);
+//   only the last pass reduces to the canonical [0,q).
+#pragma once
+#include "modarith.hpp"
+
+namespace mk {
+
+constexpr int NTT_THREADS = 256;
+constexpr int NTT_TILE = 4096;  // elements per workgroup tile (32 KiB of LDS)
+constexpr int NTT_COLS = 16;    // columns per column-pass tile: 16 x 8 B = 128-B segments
+
+struct NttTables {
+    const LimbConst *limb;  // [D]
+    const u64 *tw, *tw_sh;  // [D][N] forward psi^bitrev(k) + Shoup companions
+    const u64 *itw, *itw_sh;
+    uint32_t log_n, log_r1, log_r2;
+    uint32_t L;  // #Q limbs at full level (P limbs start at id L)
+};
+
+// forward CT butterfly on (x, y) in [0,4q): x' = x + w y, y' = x - w y (lazy)
+MK_D void ct_butterfly(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 q2) {
+    u64 u = x >= q2 ? x - q2 : x;
+    u64 v = shoup_lazy(y, w, wp, q);
+    x = u + v;
+    y = u - v + q2;
+}
+// inverse GS butterfly on (x, y) in [0,2q): x' = x + y, y' = (x - y) w (lazy)
+MK_D void gs_butterfly(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 q2) {
+    u64 s = x + y;
+    u64 d = x + q2 - y;
+    x = s >= q2 ? s - q2 : s;
+    y = shoup_lazy(d, w, wp, q);
+}
+
+// Transform `nsub` independent sub-NTTs of size 2^log_r held in LDS.
+// Element k of sub-transform g lives at lds[g*gs + k*ks].  Twiddle index at local stage s'
+// is ((base_of(g)) << s') + group.  INV selects GS order (stages high->low).
+template <bool INV, typename BaseFn>
+MK_D void lds_stages(u64 *lds, int nsub, int log_r, int gs, int ks, bool sub_fast, const u64 *tw,
+                     const u64 *tw_sh, u64 q, u64 q2, BaseFn base_of) {
+    const int half = 1 << (log_r - 1);
+    const int total = nsub * half;
+    for (int st = 0; st < log_r; ++st) {
+        const int s = INV ? (log_r - 1 - st) : st;
+        const int log_tr = log_r - 1 - s;
+        const int tr = 1 << log_tr;
+        for (int b = threadIdx.x; b < total; b += NTT_THREADS) {
+            int g, k;
+            if (sub_fast) {  // consecutive threads walk sub-transforms (columns) first
+                g = b % nsub;
+                k = b / nsub;
+            } else {  // consecutive threads walk butterflies of one sub-transform (row)
+                g = b >> (log_r - 1);
+                k = b & (half - 1);
+            }
+            const int grp = k >> log_tr;
+            const int pos = k & (tr - 1);
+            const int r0 = (grp << (log_tr + 1)) + pos;
+            const uint32_t ti = ((uint32_t)base_of(g) << s) + (uint32_t)grp;
+            const u64 w = tw[ti], wp = tw_sh[ti];
+            u64 *p0 = lds + g * gs + r0 * ks;
+            u64 *p1 = p0 + tr * ks;
+            u64 x = *p0, y = *p1;
+            if (INV) gs_butterfly(x, y, w, wp, q, q2);
+            else ct_butterfly(x, y, w, wp, q, q2);
+            *p0 = x;
+            *p1 = y;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace mk

@@ -1,0 +1,324 @@
+"""GPU parity: every C-ABI entry point vs the oracle, bit-exact on the same seeded inputs.
+
+Runs on a real MI355X (`-m gpu`).  All calls go through libmkckks_hip.so via ctypes
+(ppqsflhe_amd.binding); the oracle (oracle/liboracle.so) is only the checker.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.oracle import OracleContext, sample_gauss, sample_ternary, sample_uniform  # noqa: E402
+
+CONFIGS = {
+    # name: (log_n, depth, scaling_bits, first_bits, dnum)
+    "tiny": (10, 3, 40, 60, 2),       # L=5, K=3, alpha=3, beta=2
+    "c1": (12, 1, 40, 60, 2),         # BASELINE configs[0]: N=2^12, depth 1
+    "ref": (14, 2, 40, 60, 2),        # the reference's own CC.json
+    "c3": (16, 10, 50, 60, 3),        # BASELINE configs[1..2]: N=2^16, L=12, dnum=3
+}
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    from ppqsflhe_amd import Context
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            a = CONFIGS[name]
+            cache[name] = (Context(a[0], a[1], a[2], a[3], dnum=a[4], device=0),
+                           OracleContext(a[0], a[1], a[2], a[3], dnum=a[4]))
+        return cache[name]
+
+    yield get
+    for g, _ in cache.values():
+        g.close()
+
+
+def rand_polys(rng, ctx, limb_ids, count):
+    out = np.empty((count, len(limb_ids), ctx.N), dtype=np.uint64)
+    for j, l in enumerate(limb_ids):
+        out[:, j, :] = rng.integers(0, int(ctx.moduli[l]), size=(count, ctx.N), dtype=np.uint64)
+    return out
+
+
+def rand_ct(rng, ctx, nl, count):
+    return rand_polys(rng, ctx, list(range(nl)) * 2, count).reshape(count, 2, nl, ctx.N)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c1", "ref", "c3"])
+def test_ntt_roundtrip_and_parity(ctxs, name):
+    g, o = ctxs(name)
+    rng = np.random.default_rng(11)
+    ids = list(range(g.L)) + list(range(g.L, g.D))
+    x = rand_polys(rng, g, ids, 2)  # [2][D][N]
+    d = g.to_device(x)
+    g.ntt_forward(d, 2, g.L, with_p=True)
+    fwd = d.to_host()
+    for p in range(2):
+        for j, l in enumerate(ids):
+            assert np.array_equal(fwd[p, j], o.ntt_fwd(l, x[p, j])), (name, p, l)
+    g.ntt_inverse(d, 2, g.L, with_p=True)
+    assert np.array_equal(d.to_host(), x)
+    # inverse parity on arbitrary (non-transform) input
+    d.upload(x)
+    g.ntt_inverse(d, 2, g.L, with_p=True)
+    inv = d.to_host()
+    for j, l in enumerate(ids):
+        assert np.array_equal(inv[0, j], o.ntt_inv(l, x[0, j]))
+
+
+def test_ntt_golden_secret_keys(ctxs, golden_dir):
+    # the reference's own vectors (client_{1,2}-private.key, P4) through the HIP kernels
+    import os
+    g, _ = ctxs("ref")
+    k = np.load(os.path.join(golden_dir, "sk_ntt_kat.npz"))
+    for c in (1, 2):
+        ev = k[f"sk{c}_eval"]
+        d = g.to_device(ev[None])
+        g.ntt_inverse(d, 1, 4)
+        co = d.to_host()[0]
+        for l in range(4):
+            q = int(g.moduli[l])
+            assert np.all((co[l] == 0) | (co[l] == 1) | (co[l] == q - 1))
+        g.ntt_forward(d, 1, 4)
+        assert np.array_equal(d.to_host()[0], ev)
+
+
+@pytest.mark.parametrize("name,nl", [("tiny", 5), ("tiny", 2), ("ref", 4), ("c3", 12)])
+def test_eval_add_sum_reduce(ctxs, name, nl):
+    g, o = ctxs(name)
+    rng = np.random.default_rng(12)
+    B, C = 3, 5
+    cts = np.stack([rand_ct(rng, g, nl, B) for _ in range(C)])  # [C][B][2][nl][N]
+    d_in = g.to_device(cts)
+    d_out = g.empty((B, 2, nl, g.N))
+    g.eval_add(d_in.view(0, cts[0].shape), d_in.view(cts[0].size, cts[0].shape), d_out, B, nl)
+    got = d_out.to_host()
+    for b in range(B):
+        assert np.array_equal(got[b], o.eval_add(cts[0, b], cts[1, b]))
+    g.eval_sum(d_in, d_out, C, B, nl)
+    got = d_out.to_host()
+    for b in range(B):
+        acc = cts[0, b]
+        for c in range(1, C):
+            acc = o.eval_add(acc, cts[c, b])
+        assert np.array_equal(got[b], acc)
+    # integer-sum collective emulation: plain u64 sum then reduce_mod
+    raw = cts.sum(axis=0, dtype=np.uint64)
+    d_raw = g.to_device(raw)
+    g.reduce_mod(d_raw, B, nl, C)
+    assert np.array_equal(d_raw.to_host(), got)
+
+
+@pytest.mark.parametrize("name,nl", [("tiny", 5), ("tiny", 3), ("c1", 3), ("ref", 4), ("c3", 12)])
+def test_rescale_and_mult_const(ctxs, name, nl):
+    g, o = ctxs(name)
+    rng = np.random.default_rng(13)
+    B = 2
+    ct = rand_ct(rng, g, nl, B)
+    d_in = g.to_device(ct)
+    d_out = g.empty((B, 2, nl - 1, g.N))
+    g.rescale(d_in, d_out, B, nl)
+    got = d_out.to_host()
+    exp = [o.rescale(ct[b]) for b in range(B)]
+    for b in range(B):
+        assert np.array_equal(got[b], exp[b])
+    level = g.L - (nl - 1)
+    for operand in (0.5, 1.0 / 64, -0.25):
+        g.rescale_mult_const(d_in, d_out, B, nl, operand)
+        got = d_out.to_host()
+        f = o.const_factors(nl - 1, level, operand)
+        for b in range(B):
+            assert np.array_equal(got[b], o.mult_factors(exp[b], f))
+    d_r = g.to_device(np.stack(exp))
+    g.mult_const(d_r, B, nl - 1, 0.5)
+    f = o.const_factors(nl - 1, level, 0.5)
+    assert np.array_equal(d_r.to_host()[1], o.mult_factors(exp[1], f))
+
+
+def make_keys(o, rng):
+    N = o.N
+    s = sample_ternary(rng, N)
+    a = sample_uniform(rng, o.moduli, N)
+    e = sample_gauss(rng, N)
+    return s, a, e
+
+
+def make_rk_rand(o, rng):
+    u = np.stack([sample_ternary(rng, o.N) for _ in range(o.beta)])
+    e0 = np.stack([sample_gauss(rng, o.N) for _ in range(o.beta)])
+    e1 = np.stack([sample_gauss(rng, o.N) for _ in range(o.beta)])
+    return u, e0, e1
+
+
+@pytest.mark.parametrize("name", ["tiny", "c1", "ref", "c3"])
+def test_keygen_rekeygen_encrypt_decrypt(ctxs, name):
+    g, o = ctxs(name)
+    rng = np.random.default_rng(14)
+    N, D, L = g.N, g.D, g.L
+    s1, a1, e1 = make_keys(o, rng)
+    s2, a2, e2 = make_keys(o, rng)
+    pk1_o, sk1_o = o.keygen(s1, a1, e1)
+    pk2_o, sk2_o = o.keygen(s2, a2, e2)
+    d_pk, d_sk = g.empty((2, D, N)), g.empty((D, N))
+    g.keygen(g.to_device(s1), g.to_device(a1), g.to_device(e1), d_pk, d_sk)
+    assert np.array_equal(d_pk.to_host(), pk1_o)
+    assert np.array_equal(d_sk.to_host(), sk1_o)
+    u, r0, r1 = make_rk_rand(o, rng)
+    evk_o = o.rekeygen(s1, pk2_o, u, r0, r1)
+    d_evk = g.empty((g.beta, 2, D, N))
+    g.rekeygen(g.to_device(s1), g.to_device(pk2_o), g.to_device(u), g.to_device(r0), g.to_device(r1), d_evk)
+    assert np.array_equal(d_evk.to_host(), evk_o)
+    # encrypt at full level and at a reduced level (first nl limbs of the QP public key)
+    for nl in (L, max(2, L - 2)):
+        B = 2
+        vals = rng.uniform(-0.3, 0.3, size=(B, N // 2))
+        scale = o.sf_big(0) if nl == L else 2.0 ** 30
+        pts = np.stack([o.encode(vals[b], scale, nl) for b in range(B)])
+        v = np.stack([sample_ternary(rng, N) for _ in range(B)])
+        f0 = np.stack([sample_gauss(rng, N) for _ in range(B)])
+        f1 = np.stack([sample_gauss(rng, N) for _ in range(B)])
+        d_ct = g.empty((B, 2, nl, N))
+        g.encrypt(d_pk, g.to_device(pts), g.to_device(v), g.to_device(f0), g.to_device(f1), d_ct, B, nl)
+        got = d_ct.to_host()
+        for b in range(B):
+            assert np.array_equal(got[b], o.encrypt(pk1_o, pts[b], v[b], f0[b], f1[b]))
+        d_m = g.empty((B, nl, N))
+        g.decrypt(d_ct, d_sk, d_m, B, nl)
+        m = d_m.to_host()
+        for b in range(B):
+            assert np.array_equal(m[b], o.decrypt_core(got[b], sk1_o))
+
+
+@pytest.mark.parametrize("name", ["tiny", "ref", "c3"])
+def test_lift_ntt_matches_oracle_encode(ctxs, name):
+    # integer half of Encode: rounded scaled coefficients -> residues -> NTT.  The oracle's encode does
+    # fp64 embedding + the same rounding, so feeding its coefficient doubles must give identical residues.
+    g, o = ctxs(name)
+    rng = np.random.default_rng(15)
+    N = g.N
+    coef = np.rint(rng.normal(0, 2.0 ** 45, size=(2, N)))
+    coef[0, :4] = [2.0 ** 70 + 2.0 ** 30, -(2.0 ** 69), 0.5, -0.5]  # beyond int64; ties away from zero
+    nl = g.L
+    d_out = g.empty((2, nl, N))
+    g.lift_ntt(g.to_device(coef), d_out, 2, nl)
+    got = d_out.to_host()
+    for b in range(2):
+        ints = [int(np.sign(x) * np.floor(abs(x) + 0.5)) for x in coef[b]]
+        for l in (0, 1, nl - 1):
+            q = int(g.moduli[l])
+            res = np.array([v % q for v in ints], dtype=np.uint64)
+            assert np.array_equal(got[b, l], o.ntt_fwd(l, res))
+
+
+@pytest.mark.parametrize("name,nl", [("tiny", 5), ("tiny", 4), ("tiny", 3), ("tiny", 1), ("c1", 3), ("c1", 2),
+                                     ("ref", 4), ("ref", 3), ("c3", 12), ("c3", 11)])
+def test_modup_moddown_reencrypt(ctxs, name, nl):
+    g, o = ctxs(name)
+    rng = np.random.default_rng(16)
+    N, K, D = g.N, g.K, g.D
+    B = 3 if N <= 1 << 14 else 2
+    ext = nl + K
+    ct = rand_ct(rng, g, nl, B)
+    evk = rand_polys(rng, g, list(range(D)) * (2 * g.beta), 1).reshape(g.beta, 2, D, N)
+    nparts = g.num_parts(nl)
+    # ModUp digits
+    c1 = np.ascontiguousarray(ct[:, 1])
+    d_dig = g.empty((B, nparts, ext, N))
+    g.modup(g.to_device(c1), d_dig, B, nl)
+    dig = d_dig.to_host()
+    for b in range(B):
+        assert np.array_equal(dig[b], o.modup_digits(c1[b])), (name, nl, b)
+    # ModDown
+    ids = list(range(nl)) + list(range(g.L, D))
+    x = rand_polys(rng, g, ids, B)
+    d_md = g.empty((B, nl, N))
+    g.moddown(g.to_device(x), d_md, B, nl)
+    md = d_md.to_host()
+    for b in range(B):
+        assert np.array_equal(md[b], o.moddown(x[b]))
+    # full ReEncrypt, out of place and in place
+    d_ct, d_evk, d_out = g.to_device(ct), g.to_device(evk), g.empty((B, 2, nl, N))
+    g.reencrypt(d_ct, d_evk, d_out, B, nl)
+    got = d_out.to_host()
+    exp = [o.reencrypt(ct[b], evk) for b in range(B)]
+    for b in range(B):
+        assert np.array_equal(got[b], exp[b]), (name, nl, b)
+    g.reencrypt(d_ct, d_evk, d_ct, B, nl)
+    assert np.array_equal(d_ct.to_host(), got)
+
+
+def test_reencrypt_batch_larger_than_chunk(ctxs):
+    g, o = ctxs("tiny")
+    rng = np.random.default_rng(17)
+    B, nl = 11, g.L
+    ct = rand_ct(rng, g, nl, B)
+    evk = rand_polys(rng, g, list(range(g.D)) * (2 * g.beta), 1).reshape(g.beta, 2, g.D, g.N)
+    d_out = g.empty((B, 2, nl, g.N))
+    g.reencrypt(g.to_device(ct), g.to_device(evk), d_out, B, nl)
+    got = d_out.to_host()
+    for b in range(B):
+        assert np.array_equal(got[b], o.reencrypt(ct[b], evk))
+
+
+def test_full_round_known_answer(ctxs, golden_dir):
+    """The reference's round (run.sh:28-44) on the GPU at the reference's own parameters, checked against the
+    reference's plaintext-in / decrypted-out fixture (P8) and bit-exactly against the oracle."""
+    import os
+    g, o = ctxs("ref")
+    W = np.load(os.path.join(golden_dir, "e2e_weights.npz"))
+    rng = np.random.default_rng(18)
+    N, D, L = g.N, g.D, g.L
+    keys = []
+    for _ in range(2):
+        s, a, e = make_keys(o, rng)
+        pk, sk = o.keygen(s, a, e)
+        keys.append((s, pk, sk))
+    u, r0, r1 = make_rk_rand(o, rng)
+    rk12 = o.rekeygen(keys[0][0], keys[1][1], u, r0, r1)
+    u, r0, r1 = make_rk_rand(o, rng)
+    rk21 = o.rekeygen(keys[1][0], keys[0][1], u, r0, r1)
+    v1, v2 = W["sample_c1_param_1_values"], W["sample_c2_param_1_values"]
+
+    def enc(pk, vals):
+        pt = o.encode(vals, o.sf_big(0), L)
+        return o.encrypt(pk, pt, sample_ternary(rng, N), sample_gauss(rng, N), sample_gauss(rng, N))
+
+    ct1, ct2 = enc(keys[0][1], v1), enc(keys[1][1], v2)
+    d1, d2 = g.to_device(ct1[None]), g.to_device(ct2[None])
+    d12 = g.empty((1, 2, L, N))
+    g.reencrypt(d1, g.to_device(rk12), d12, 1, L)          # changeCipherDomain c1 -> c2
+    d_sum = g.empty((1, 2, L, N))
+    g.eval_add(d12, d2, d_sum, 1, L)                        # EvalAdd
+    d_avg = g.empty((1, 2, L - 1, N))
+    g.rescale_mult_const(d_sum, d_avg, 1, L, 0.5)           # EvalMult(., 0.5)
+    d_back = g.empty((1, 2, L - 1, N))
+    g.reencrypt(d_avg, g.to_device(rk21), d_back, 1, L - 1)  # changeCipherDomain c2 -> c1
+    # oracle, same inputs
+    s_o = o.eval_add(o.reencrypt(ct1, rk12), ct2)
+    avg_o = o.mult_factors(o.rescale(s_o), o.const_factors(L - 1, 1, 0.5))
+    back_o = o.reencrypt(avg_o, rk21)
+    assert np.array_equal(d_avg.to_host()[0], avg_o)
+    assert np.array_equal(d_back.to_host()[0], back_o)
+    # decrypt on the GPU, decode with the oracle's decoder, compare with the fixture
+    d_m = g.empty((1, L - 1, N))
+    g.decrypt(d_back, g.to_device(keys[0][2]), d_m, 1, L - 1)
+    assert np.array_equal(d_m.to_host()[0], o.decrypt_core(back_o, keys[0][2]))
+    dec = o.decrypt_decode(back_o, keys[0][2], o.sf(1) ** 2)[: v1.size]
+    mean = (v1 + v2) / 2
+    assert np.abs(dec - mean).max() < 2.0 ** -25
+    assert np.abs(dec - W["decrypted_c1_param_1_values"]).max() < 2.0 ** -24
+
+
+def test_errors_are_loud(ctxs):
+    from ppqsflhe_amd import MkckksError
+    g, _ = ctxs("tiny")
+    d = g.empty((1, 2, g.L, g.N))
+    with pytest.raises(MkckksError):
+        g.eval_add(d, d, d, 1, g.L + 1)
+    with pytest.raises(MkckksError):
+        g.rescale(d, d, 1, 1)
+    with pytest.raises(MkckksError):
+        g.reduce_mod(d, 1, g.L, 9)

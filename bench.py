@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- ciphertexts/sec aggregated + PRE at N=2^16, L=12 (BASELINE.json metric).
+
+One step = one pass of the hot path over one batch of synthetic client ciphertexts already resident in HBM:
+    for each of C clients:  reencrypt_batch (hybrid key-switch PRE into the common key domain)   [SURVEY 8a a4]
+    eval_sum over the C clients (coefficient-wise modular add)                                   [a5]
+    (N>1 GPUs: RCCL reduce-scatter of the per-GPU partial sums as uint64 + reduce_mod)          [8e]
+    rescale_mult_const(1/n_clients_total)  (EvalMult(ct, 1/n): rescale then integer constant)    [a6]
+Unit of work = one client ciphertext PRE'd and folded into the aggregate (92.7 MB algorithmic).
+Weak scaling: every GPU holds its own C clients x B ciphertexts; `value` = all ranks' units / max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 5 --warmup 2
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_MEASURED_GBS = 6290.0
+
+
+def algorithmic_bytes_per_unit(N, L, K, beta, n_clients):
+    """compulsory traffic per client ciphertext PRE'd and folded into the aggregate."""
+    limb = 8 * N
+    D = L + K
+    pre = limb * (2 * L + 2 * beta * D + 2 * L)          # ct in + evk + ct out
+    agg = limb * 2 * L * (1 + 1.0 / n_clients)            # read it once more, write 1/n of the sum
+    resc = limb * (2 * L + 2 * (L - 1)) / n_clients       # rescale + const-mul of the sum, amortised
+    return pre + agg + resc
+
+
+def cpu_baseline(args, log):
+    """The oracle (CPU restatement, OpenMP over limbs like OpenFHE's WITH_OPENMP build) on a bounded sample of
+    the same workload: `pre` ciphertexts PRE'd, summed, one rescale*const.  kind = "port"."""
+    from oracle.oracle import OracleContext
+    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    t0 = time.time()
+    o = OracleContext(args.log_n, args.depth, args.scaling_bits, 60, dnum=args.dnum)
+    log(f"[cpu] oracle context built in {time.time() - t0:.1f}s, threads={threads}")
+    rng = np.random.default_rng(1)
+    N, L, D = o.N, o.L, o.D
+
+    def rnd(ids):
+        out = np.empty((len(ids), N), dtype=np.uint64)
+        for j, l in enumerate(ids):
+            out[j] = rng.integers(0, int(o.moduli[l]), size=N, dtype=np.uint64)
+        return out
+
+    evk = rnd(list(range(D)) * (2 * o.beta)).reshape(o.beta, 2, D, N)
+    n_pre = args.cpu_sample
+    pool = [rnd(list(range(L)) * 2).reshape(2, L, N) for _ in range(4)]
+    o.reencrypt(pool[0], evk)  # untimed warm-up (page faults, OpenMP team start)
+    cts = [pool[i % 4] for i in range(n_pre)]
+    f = o.const_factors(L - 1, 1, 1.0 / n_pre)
+    t0 = time.time()
+    acc = None
+    for ct in cts:
+        r = o.reencrypt(ct, evk)
+        acc = r if acc is None else o.eval_add(acc, r)
+    o.mult_factors(o.rescale(acc), f)
+    dt = time.time() - t0
+    # amortise the single rescale the same way the GPU step does (1 per n_clients units)
+    return {"value": n_pre / dt, "unit": "ciphertexts/s", "cores": threads, "kind": "port",
+            "sample": f"{n_pre} ciphertexts PRE'd + summed + 1 rescale*const at N=2^{args.log_n}, L={L}, "
+                      f"dnum={args.dnum}; oracle/liboracle.so (OpenMP over limbs), {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=16)
+    ap.add_argument("--depth", type=int, default=10, help="mult depth; L = depth + 2 = 12")
+    ap.add_argument("--scaling-bits", type=int, default=50)
+    ap.add_argument("--dnum", type=int, default=3)
+    ap.add_argument("--clients", type=int, default=8, help="clients per GPU")
+    ap.add_argument("--cts", type=int, default=8, help="ciphertexts per client (multiple of --gpus)")
+    ap.add_argument("--cpu-sample", type=int, default=96, help="ciphertexts in the CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ppqsflhe_amd import Context
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+
+    def log(msg):
+        if rank == 0:
+            print(msg, file=sys.stderr, flush=True)
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    if args.cts % world:
+        raise SystemExit("--cts must be a multiple of --gpus")
+
+    ctx = Context(args.log_n, args.depth, args.scaling_bits, 60, dnum=args.dnum, device=local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    N, L, K, D, beta = ctx.N, ctx.L, ctx.K, ctx.D, ctx.beta
+    C, B = args.clients, args.cts
+    log(f"[bench] N=2^{args.log_n} L={L} K={K} dnum={args.dnum} beta={beta}; {C} clients x {B} ct per GPU, {world} GPU(s)")
+
+    # synthetic inputs, generated in HBM: residues uniform in [0, q_i), seeded per rank
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+
+    def uniform(shape_lead, ids):
+        t = torch.empty(*shape_lead, len(ids), N, dtype=torch.int64, device=dev)
+        for j, l in enumerate(ids):
+            t[..., j, :] = torch.randint(0, int(ctx.moduli[l]), (*shape_lead, N), generator=gen, device=dev,
+                                         dtype=torch.int64)
+        return t
+
+    ct_in = uniform((C, B), list(range(L)) * 2).view(C, B, 2, L, N)
+    evk = uniform((C,), list(range(D)) * (2 * beta)).view(C, beta, 2, D, N)
+    pre = torch.empty_like(ct_in)
+    agg = torch.empty(B, 2, L, N, dtype=torch.int64, device=dev)
+    Bs = B // world
+    shard = torch.empty(Bs, 2, L, N, dtype=torch.int64, device=dev) if world > 1 else agg
+    out = torch.empty(Bs, 2, L - 1, N, dtype=torch.int64, device=dev)
+    inv_n = 1.0 / (C * world)
+
+    def step():
+        for c in range(C):
+            ctx.reencrypt(ct_in[c], evk[c], pre[c], B, L)
+        ctx.eval_sum(pre, agg, C, B, L)
+        if world > 1:
+            # per-GPU partial sums are canonical (< 2^61): an integer sum over <= 8 ranks cannot wrap 2^64
+            dist.reduce_scatter_tensor(shard, agg, op=dist.ReduceOp.SUM)
+            ctx.reduce_mod(shard, Bs, L, world)
+        ctx.rescale_mult_const(shard, out, Bs, L, inv_n)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    fence()
+    dt = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels run on
+    if world > 1:
+        t = torch.tensor([dt, gpu_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, gpu_ms = float(t[0]), float(t[1])
+
+    units_per_step = C * B * world
+    value = units_per_step * args.steps / dt
+    bytes_unit = algorithmic_bytes_per_unit(N, L, K, beta, C * world)
+    # one "launch" of the hot path = one step on one GPU (all of its kernels, serialised on one stream)
+    step_s_gpu = gpu_ms / 1e3 / args.steps
+    achieved = bytes_unit * C * B / step_s_gpu / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(prof):
+        try:
+            rec = json.load(open(prof))
+            key = f"logn{args.log_n}_L{L}_dnum{args.dnum}_C{C}_B{B}"
+            traffic = rec.get(key, {}).get("hbm_bytes_per_step")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "ciphertexts/sec aggregated+PRE at N=2^16, L=12 RNS limbs",
+        "value": value, "unit": "ciphertexts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"C3+C4: {C} clients x {B} ct per GPU, N=2^{args.log_n}, L={L}, K={K}, dnum={args.dnum}: "
+                               "reencrypt_batch (hybrid key-switch PRE) -> eval_sum -> "
+                               + ("RCCL reduce_scatter(u64 sum)+reduce_mod -> " if world > 1 else "")
+                               + "rescale_mult_const(1/n)",
+                   "ring_dim": N, "limbs": L, "special_limbs": K, "dnum": args.dnum, "clients_per_gpu": C,
+                   "ct_per_client": B, "units_per_step": units_per_step, "sharding": f"clients x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_unit": bytes_unit, "units_per_launch": C * B,
+                     "launch": "one hot-path step on one GPU (all kernels of the path, one stream)",
+                     "launch_ms": step_s_gpu * 1e3, "frac_of_measured_copy_peak": achieved / HBM_MEASURED_GBS},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        try:
+            result["cpu_baseline"] = cpu_baseline(args, log)
+        except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
+            result["cpu_baseline"] = {"value": None, "unit": "ciphertexts/s", "cores": 0, "kind": "port",
+                                      "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@
 // streams 8-B (or 16-B) words with unit stride per lane; the limb (modulus) is uniform per
 // workgroup (blockIdx.y), so all per-limb constants sit in SGPRs.
 #include "engine.hpp"
+#include "ntt_radix.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -22,20 +23,6 @@ namespace mk {
 // =====================================================================================
 // NTT kernels (schedule described in ntt_kernels.hpp)
 // =====================================================================================
-
-struct NttIo {
-    const u64 *in;
-    u64 *out;
-    size_t in_stride, out_stride;  // words between consecutive polynomials
-    uint32_t in_slot0, out_slot0;  // first limb slot touched inside a polynomial
-    uint32_t vslot0;               // virtual slot of the first limb (decides the limb id)
-    uint32_t nslots;               // limbs per polynomial handled by this launch
-    uint32_t nl;                   // #Q limbs of the polynomial (slots >= nl are P limbs)
-};
-
-__device__ __forceinline__ uint32_t limb_id_of(uint32_t vslot, uint32_t nl, uint32_t L) {
-    return vslot < nl ? vslot : L + (vslot - nl);
-}
 
 template <bool INV>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col(NttIo io, NttTables T, const u64 *scale,
@@ -421,8 +408,11 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
     tabs_.limb = d_limb_;
     tabs_.tw = d_tw_; tabs_.tw_sh = d_tw_sh_; tabs_.itw = d_itw_; tabs_.itw_sh = d_itw_sh_;
     tabs_.log_n = ps_.log_n;
-    tabs_.log_r1 = ps_.log_n / 2;
+    // N = R1 x R2 with R1 <= R2; even splits of even log N land on the radix-H kernels (16/64/256)
+    tabs_.log_r1 = (ps_.log_n % 2 == 0) ? ((ps_.log_n / 2) & ~1u) : ps_.log_n / 2;
     tabs_.log_r2 = ps_.log_n - tabs_.log_r1;
+    if (const char *e = std::getenv("MKCKKS_GENERIC_NTT"))
+        if (std::atoi(e) == 1) { tabs_.log_r1 = ps_.log_n / 2; tabs_.log_r2 = ps_.log_n - tabs_.log_r1; }
     tabs_.L = ps_.L;
 }
 
@@ -555,24 +545,58 @@ static void launch_baseconv(const u64 *in, size_t in_stride, u64 *out, size_t ou
 
 // ---- transforms ---------------------------------------------------------------------
 
-// generic two-pass launcher: reads `io.in`, leaves the result in `io.out` (may be the same buffer)
+// radix-H register kernels exist for sub-transform sizes 16, 64, 256 (H = 4, 8, 16) and need at least
+// S = 256/H columns (rows) for the column (row) pass; everything else takes the generic LDS-stage kernels.
+static int fast_log_h(uint32_t log_r, uint32_t other_extent) {
+    if (log_r != 4 && log_r != 6 && log_r != 8) return 0;
+    const uint32_t h = 1u << (log_r / 2);
+    return (256u / h) <= other_extent ? (int)(log_r / 2) : 0;
+}
+
+template <bool INV>
+static void launch_col(const NttIo &io, const NttTables &T, uint32_t n_polys, const u64 *scale, const u64 *scale_sh,
+                       hipStream_t s) {
+    const uint32_t r1 = 1u << T.log_r1, r2 = 1u << T.log_r2;
+    const uint32_t items = n_polys * io.nslots;
+    switch (fast_log_h(T.log_r1, r2)) {
+        case 4: k_ntt_col_r<4, INV><<<dim3(r2 / 16, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh); break;
+        case 3: k_ntt_col_r<3, INV><<<dim3(r2 / 32, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh); break;
+        case 2: k_ntt_col_r<2, INV><<<dim3(r2 / 64, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh); break;
+        default:
+            k_ntt_col<INV><<<dim3(r2 / NTT_COLS, items), NTT_THREADS, (size_t)r1 * NTT_COLS * sizeof(u64), s>>>(
+                io, T, scale, scale_sh);
+    }
+}
+
+template <bool INV>
+static void launch_row(const NttIo &io, const NttTables &T, uint32_t n_polys, hipStream_t s) {
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
+    const uint32_t items = n_polys * io.nslots;
+    switch (fast_log_h(T.log_r2, r1)) {
+        case 4: k_ntt_row_r<4, INV><<<dim3(r1 / 16, items), NTT_THREADS, 0, s>>>(io, T); break;
+        case 3: k_ntt_row_r<3, INV><<<dim3(r1 / 32, items), NTT_THREADS, 0, s>>>(io, T); break;
+        case 2: k_ntt_row_r<2, INV><<<dim3(r1 / 64, items), NTT_THREADS, 0, s>>>(io, T); break;
+        default: {
+            const uint32_t tile = n < (uint32_t)NTT_TILE ? n : (uint32_t)NTT_TILE;
+            k_ntt_row<INV><<<dim3(n / tile, items), NTT_THREADS, (size_t)tile * sizeof(u64), s>>>(io, T);
+        }
+    }
+}
+
+// two-pass launcher: reads `io.in`, leaves the result in `io.out` (may be the same buffer)
 static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inverse, const u64 *scale,
                        const u64 *scale_sh, hipStream_t s) {
     if (n_polys == 0 || io.nslots == 0) return;
-    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1, r2 = 1u << T.log_r2;
-    const uint32_t tile = n < (uint32_t)NTT_TILE ? n : (uint32_t)NTT_TILE;
-    const dim3 gcol(r2 / NTT_COLS, n_polys * io.nslots), grow(n / tile, n_polys * io.nslots);
-    const size_t lds_col = (size_t)r1 * NTT_COLS * sizeof(u64), lds_row = (size_t)tile * sizeof(u64);
     NttIo second = io;  // second pass runs in place on the output
     second.in = io.out;
     second.in_stride = io.out_stride;
     second.in_slot0 = io.out_slot0;
     if (!inverse) {
-        k_ntt_col<false><<<gcol, NTT_THREADS, lds_col, s>>>(io, T, nullptr, nullptr);
-        k_ntt_row<false><<<grow, NTT_THREADS, lds_row, s>>>(second, T);
+        launch_col<false>(io, T, n_polys, nullptr, nullptr, s);
+        launch_row<false>(second, T, n_polys, s);
     } else {
-        k_ntt_row<true><<<grow, NTT_THREADS, lds_row, s>>>(io, T);
-        k_ntt_col<true><<<gcol, NTT_THREADS, lds_col, s>>>(second, T, scale, scale_sh);
+        launch_row<true>(io, T, n_polys, s);
+        launch_col<true>(second, T, n_polys, scale, scale_sh, s);
     }
     MK_HIP(hipGetLastError());
 }

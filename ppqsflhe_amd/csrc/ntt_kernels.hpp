@@ -36,6 +36,20 @@ struct NttTables {
     uint32_t L;  // #Q limbs at full level (P limbs start at id L)
 };
 
+struct NttIo {
+    const u64 *in;
+    u64 *out;
+    size_t in_stride, out_stride;  // words between consecutive polynomials
+    uint32_t in_slot0, out_slot0;  // first limb slot touched inside a polynomial
+    uint32_t vslot0;               // virtual slot of the first limb (decides the limb id)
+    uint32_t nslots;               // limbs per polynomial handled by this launch
+    uint32_t nl;                   // #Q limbs of the polynomial (slots >= nl are P limbs)
+};
+
+MK_D uint32_t limb_id_of(uint32_t vslot, uint32_t nl, uint32_t L) {
+    return vslot < nl ? vslot : L + (vslot - nl);
+}
+
 // forward CT butterfly on (x, y) in [0,4q): x' = x + w y, y' = x - w y (lazy)
 MK_D void ct_butterfly(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 q2) {
     u64 u = x >= q2 ? x - q2 : x;

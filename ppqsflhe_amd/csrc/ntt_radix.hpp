@@ -1,0 +1,206 @@
+// ntt_radix.hpp -- register-resident radix-H NTT rounds for gfx950 (H = 4, 8, 16).
+//
+// A sub-transform of R = H*H points is done in two rounds of log2(H) butterfly stages each.
+// In a round every thread holds H elements in VGPRs and all its twiddles, so the only
+// cross-thread traffic is ONE LDS exchange between the rounds (the v0 kernel in
+// ntt_kernels.hpp did log2(R) LDS round trips with a dependent twiddle load per stage).
+//
+//   forward (Cooley-Tukey, large strides first):
+//     round A: thread j holds x[j + H k], k < H      stages 0..log H-1     base_eff = base
+//     round B: thread j holds x[H j + k], k < H      stages log H..2log H-1 base_eff = base*H + j
+//   inverse (Gentleman-Sande) runs round B then round A with the stages reversed.
+//   Twiddle of in-register stage s, group g (g < 2^s): table[(base_eff << s) + g].
+#pragma once
+#include "modarith.hpp"
+#include "ntt_kernels.hpp"
+
+namespace mk {
+
+// twiddles of one round: w[(1<<s) - 1 + g] = table[(base_eff << s) + g]
+template <int LOG_H>
+MK_D void load_round_twiddles(const u64 *__restrict__ tw, const u64 *__restrict__ tw_sh, uint32_t base_eff,
+                              u64 (&w)[(1 << LOG_H) - 1], u64 (&wp)[(1 << LOG_H) - 1]) {
+#pragma unroll
+    for (int s = 0; s < LOG_H; ++s) {
+        const uint32_t first = base_eff << s;
+#pragma unroll
+        for (int g = 0; g < (1 << s); ++g) {
+            w[(1 << s) - 1 + g] = tw[first + g];
+            wp[(1 << s) - 1 + g] = tw_sh[first + g];
+        }
+    }
+}
+
+// log2(H) forward stages on H registers; values stay in [0,4q)
+template <int LOG_H>
+MK_D void radix_forward(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], const u64 (&wp)[(1 << LOG_H) - 1],
+                        u64 q, u64 q2) {
+    constexpr int H = 1 << LOG_H;
+#pragma unroll
+    for (int s = 0; s < LOG_H; ++s) {
+        const int dist = H >> (s + 1);
+#pragma unroll
+        for (int p = 0; p < H / 2; ++p) {
+            const int g = p / dist, k0 = g * 2 * dist + (p % dist);
+            ct_butterfly(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wp[(1 << s) - 1 + g], q, q2);
+        }
+    }
+}
+
+// log2(H) inverse stages on H registers (stage order reversed); values stay in [0,2q)
+template <int LOG_H>
+MK_D void radix_inverse(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], const u64 (&wp)[(1 << LOG_H) - 1],
+                        u64 q, u64 q2) {
+    constexpr int H = 1 << LOG_H;
+#pragma unroll
+    for (int s = LOG_H - 1; s >= 0; --s) {
+        const int dist = H >> (s + 1);
+#pragma unroll
+        for (int p = 0; p < H / 2; ++p) {
+            const int g = p / dist, k0 = g * 2 * dist + (p % dist);
+            gs_butterfly(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wp[(1 << s) - 1 + g], q, q2);
+        }
+    }
+}
+
+MK_D u64 canon4(u64 v, u64 q, u64 q2) {  // [0,4q) -> [0,q)
+    v = v >= q2 ? v - q2 : v;
+    return v >= q ? v - q : v;
+}
+
+// ---- LDS layouts -------------------------------------------------------------------
+// column tile: R rows x S columns (S = 256/H), stored as H blocks of H rows; blocks are padded by
+// 16 words when S == 16 so that two neighbouring blocks land in different halves of a bank row.
+template <int LOG_H>
+struct ColTile {
+    static constexpr int H = 1 << LOG_H, S = 256 / H, BLK = H * S + (S == 16 ? 16 : 0);
+    static constexpr int WORDS = H * BLK;
+    // row = blk*H + kk
+    static MK_D int at(int blk, int kk, int c) { return blk * BLK + kk * S + c; }
+};
+// row tile: S rows of R contiguous words; one pad word per H words, row stride R + H
+template <int LOG_H>
+struct RowTile {
+    static constexpr int H = 1 << LOG_H, S = 256 / H, R = H * H, RS = R + H;
+    static constexpr int WORDS = S * RS;
+    static MK_D int at(int g, int x) { return g * RS + x + (x >> LOG_H); }
+};
+
+// ---- kernels -----------------------------------------------------------------------
+
+// Column pass over R1 = H*H rows: one workgroup = S = 256/H adjacent columns.  Global accesses are
+// S x 8-B row segments (128 B at H = 16); one LDS exchange between the two rounds.
+template <int LOG_H, bool INV>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T, const u64 *scale,
+                                                           const u64 *scale_sh) {
+    using TL = ColTile<LOG_H>;
+    constexpr int H = TL::H, S = TL::S;
+    __shared__ u64 lds[TL::WORDS];
+    const uint32_t poly = blockIdx.y / io.nslots, sl = blockIdx.y % io.nslots;
+    const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
+    const LimbConst lc = T.limb[id];
+    const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2;
+    const int c = threadIdx.x % S, j = threadIdx.x / S;
+    const u64 *src = io.in + (size_t)poly * io.in_stride + (size_t)(io.in_slot0 + sl) * n + blockIdx.x * S + c;
+    u64 *dst = io.out + (size_t)poly * io.out_stride + (size_t)(io.out_slot0 + sl) * n + blockIdx.x * S + c;
+    const u64 *tw = (INV ? T.itw : T.tw) + (size_t)id * n;
+    const u64 *tw_sh = (INV ? T.itw_sh : T.tw_sh) + (size_t)id * n;
+    u64 x[H], w[H - 1], wp[H - 1];
+    if (!INV) {
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = src[(size_t)(j + H * k) * r2];
+        load_round_twiddles<LOG_H>(tw, tw_sh, 1u, w, wp);  // same for every column: scalar loads
+        radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(k, j, c)] = x[k];  // row j + H k
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(j, k, c)];  // row H j + k
+        load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w, wp);
+        radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
+#pragma unroll
+        for (int k = 0; k < H; ++k) dst[(size_t)(H * j + k) * r2] = x[k];  // lazy [0,4q): the row pass finishes
+    } else {
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = src[(size_t)(H * j + k) * r2];
+        load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w, wp);
+        radix_inverse<LOG_H>(x, w, wp, lc.q, lc.q2);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(j, k, c)] = x[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(k, j, c)];
+        load_round_twiddles<LOG_H>(tw, tw_sh, 1u, w, wp);
+        radix_inverse<LOG_H>(x, w, wp, lc.q, lc.q2);
+        const u64 sc = scale ? scale[id] : lc.ninv, sc_sh = scale ? scale_sh[id] : lc.ninv_sh;
+#pragma unroll
+        for (int k = 0; k < H; ++k) dst[(size_t)(j + H * k) * r2] = shoup_mul(x[k], sc, sc_sh, lc.q);
+    }
+}
+
+// Row pass over rows of R2 = H*H contiguous words: one workgroup = S consecutive rows (S*R2 contiguous
+// words).  The side that needs per-thread contiguous runs goes through LDS with coalesced 16-B accesses.
+template <int LOG_H, bool INV>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T) {
+    using TL = RowTile<LOG_H>;
+    constexpr int H = TL::H, S = TL::S, R = TL::R;
+    __shared__ u64 lds[TL::WORDS];
+    const uint32_t poly = blockIdx.y / io.nslots, sl = blockIdx.y % io.nslots;
+    const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
+    const LimbConst lc = T.limb[id];
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
+    const uint32_t row0 = blockIdx.x * S;
+    const int g = threadIdx.x / H, j = threadIdx.x % H;
+    const u64 *src = io.in + (size_t)poly * io.in_stride + (size_t)(io.in_slot0 + sl) * n + (size_t)row0 * R;
+    u64 *dst = io.out + (size_t)poly * io.out_stride + (size_t)(io.out_slot0 + sl) * n + (size_t)row0 * R;
+    const u64 *tw = (INV ? T.itw : T.tw) + (size_t)id * n;
+    const u64 *tw_sh = (INV ? T.itw_sh : T.tw_sh) + (size_t)id * n;
+    const uint32_t base = r1 + row0 + g;
+    u64 x[H], w[H - 1], wp[H - 1];
+    if (!INV) {
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = src[(size_t)g * R + j + H * k];
+        load_round_twiddles<LOG_H>(tw, tw_sh, base, w, wp);
+        radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
+        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);
+        radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = canon4(x[k], lc.q, lc.q2);  // own words only
+        __syncthreads();
+        for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
+            const int gg = (2 * e) / R, xx = (2 * e) % R;
+            ulong2 v;
+            v.x = lds[TL::at(gg, xx)];
+            v.y = lds[TL::at(gg, xx + 1)];
+            reinterpret_cast<ulong2 *>(dst)[e] = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
+            const int gg = (2 * e) / R, xx = (2 * e) % R;
+            const ulong2 v = reinterpret_cast<const ulong2 *>(src)[e];
+            lds[TL::at(gg, xx)] = v.x;
+            lds[TL::at(gg, xx + 1)] = v.y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
+        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);
+        radix_inverse<LOG_H>(x, w, wp, lc.q, lc.q2);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = x[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, j + H * k)];
+        load_round_twiddles<LOG_H>(tw, tw_sh, base, w, wp);
+        radix_inverse<LOG_H>(x, w, wp, lc.q, lc.q2);
+#pragma unroll
+        for (int k = 0; k < H; ++k) dst[(size_t)g * R + j + H * k] = x[k];  // lazy [0,2q): the column pass scales
+    }
+}
+
+}  // namespace mk

@@ -69,6 +69,28 @@ def test_ntt_roundtrip_and_parity(ctxs, name):
         assert np.array_equal(inv[0, j], o.ntt_inv(l, x[0, j]))
 
 
+@pytest.mark.parametrize("log_n,generic", [(9, False), (11, False), (13, False), (17, False), (12, True), (16, True)])
+def test_ntt_other_sizes_and_generic_kernels(log_n, generic, monkeypatch):
+    # odd log N and N = 2^17 take the generic LDS-stage kernels for one or both passes; MKCKKS_GENERIC_NTT=1
+    # forces them everywhere.  Both schedules must give the same bits as the oracle.
+    from ppqsflhe_amd import Context
+    if generic:
+        monkeypatch.setenv("MKCKKS_GENERIC_NTT", "1")
+    g = Context(log_n, 1, 40, 60, dnum=2, device=0)
+    o = OracleContext(log_n, 1, 40, 60, dnum=2)
+    rng = np.random.default_rng(21)
+    ids = list(range(g.L)) + list(range(g.L, g.D))
+    x = rand_polys(rng, g, ids, 1)
+    d = g.to_device(x)
+    g.ntt_forward(d, 1, g.L, with_p=True)
+    fwd = d.to_host()
+    for j, l in enumerate(ids):
+        assert np.array_equal(fwd[0, j], o.ntt_fwd(l, x[0, j])), (log_n, l)
+    g.ntt_inverse(d, 1, g.L, with_p=True)
+    assert np.array_equal(d.to_host(), x)
+    g.close()
+
+
 def test_ntt_golden_secret_keys(ctxs, golden_dir):
     # the reference's own vectors (client_{1,2}-private.key, P4) through the HIP kernels
     import os

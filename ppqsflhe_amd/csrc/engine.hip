@@ -29,6 +29,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col(NttIo io, NttTables T, 
                                                          const u64 *scale_sh) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const uint32_t poly = blockIdx.y / io.nslots, s = blockIdx.y % io.nslots;
+    if (ntt_slot_skipped(io, poly, io.vslot0 + s)) return;  // block-uniform
     const uint32_t id = limb_id_of(io.vslot0 + s, io.nl, T.L);
     const LimbConst lc = T.limb[id];
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1, r2 = 1u << T.log_r2;
@@ -69,6 +70,7 @@ template <bool INV>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row(NttIo io, NttTables T) {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const uint32_t poly = blockIdx.y / io.nslots, s = blockIdx.y % io.nslots;
+    if (ntt_slot_skipped(io, poly, io.vslot0 + s)) return;  // block-uniform
     const uint32_t id = limb_id_of(io.vslot0 + s, io.nl, T.L);
     const LimbConst lc = T.limb[id];
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1, r2 = 1u << T.log_r2;
@@ -247,7 +249,7 @@ __global__ void k_copy_slots(const u64 *in, size_t in_stride, uint32_t in_slot0,
 // ApproxSwitchCRTBasis: one thread per coefficient.  in: [items][*][N] COEFFICIENT, canonical.
 template <int N_IN>
 __global__ void k_baseconv(const u64 *in, size_t in_stride, u64 *out, size_t out_stride, DevConv cv,
-                           const LimbConst *limb, uint32_t n) {
+                           const LimbConst *limb, uint32_t n, int prescaled) {
     const uint32_t idx = blockIdx.x * EW_THREADS + threadIdx.x;
     const uint32_t item = blockIdx.y;
     if (idx >= n) return;
@@ -255,7 +257,8 @@ __global__ void k_baseconv(const u64 *in, size_t in_stride, u64 *out, size_t out
 #pragma unroll
     for (int i = 0; i < N_IN; ++i) {
         const u64 x = in[(size_t)item * in_stride + (size_t)cv.src_slot[i] * n + idx];
-        t[i] = shoup_mul(x, cv.hatinv[i], cv.hatinv_sh[i], limb[cv.src_id[i]].q);
+        // prescaled: the inverse transform already folded [(S/s_i)^-1]_{s_i} into its N^-1 scaling
+        t[i] = prescaled ? x : shoup_mul(x, cv.hatinv[i], cv.hatinv_sh[i], limb[cv.src_id[i]].q);
     }
     for (uint32_t j = 0; j < cv.n_out; ++j) {
         u64 hi = 0, lo = 0;
@@ -288,6 +291,47 @@ __global__ void k_inner_product(const u64 *digits, const u64 *evk, u64 *ctilde, 
     r1.y = reduce_wide(h1y, l1y, lc);
     st2(ctilde + (((size_t)item * 2 + 0) * ext + slot) * g.n + idx, r0);
     st2(ctilde + (((size_t)item * 2 + 1) * ext + slot) * g.n + idx, r1);
+}
+
+// EvalFastKeySwitchCoreExt, batch form: one workgroup owns a (limb, coefficient range) and keeps the eval-key
+// words b_j, a_j of all NPARTS digits in registers while it walks the `items` ciphertexts of the batch, so the
+// eval key is streamed from HBM once per launch instead of once per ciphertext.  The digit's own limbs are read
+// straight from c1 (no copy into the digit buffer).
+template <int NPARTS>
+__global__ void k_inner_product_b(const u64 *digits, const u64 *c1, size_t c1_stride, const u64 *evk, u64 *ctilde,
+                                  EwGeom g, const LimbConst *limb, uint32_t ext, uint32_t D, uint32_t alpha,
+                                  uint32_t items) {
+    const uint32_t slot = blockIdx.y;
+    const uint32_t idx = (blockIdx.x * EW_THREADS + threadIdx.x) * 2;
+    if (idx >= g.n) return;
+    const uint32_t id = limb_id_of(slot, g.nl, g.L);
+    const LimbConst lc = limb[id];
+    const int own = slot < g.nl ? (int)(slot / alpha) : -1;
+    ulong2 b[NPARTS], a[NPARTS];
+#pragma unroll
+    for (int j = 0; j < NPARTS; ++j) {
+        b[j] = ld2(evk + (((size_t)j * 2 + 0) * D + id) * g.n + idx);
+        a[j] = ld2(evk + (((size_t)j * 2 + 1) * D + id) * g.n + idx);
+    }
+    for (uint32_t item = 0; item < items; ++item) {
+        u64 h0x = 0, l0x = 0, h0y = 0, l0y = 0, h1x = 0, l1x = 0, h1y = 0, l1y = 0;
+#pragma unroll
+        for (int j = 0; j < NPARTS; ++j) {
+            const ulong2 d = (j == own) ? ld2(c1 + (size_t)item * c1_stride + (size_t)slot * g.n + idx)
+                                        : ld2(digits + (((size_t)item * NPARTS + j) * ext + slot) * g.n + idx);
+            mac128(h0x, l0x, d.x, b[j].x);
+            mac128(h0y, l0y, d.y, b[j].y);
+            mac128(h1x, l1x, d.x, a[j].x);
+            mac128(h1y, l1y, d.y, a[j].y);
+        }
+        ulong2 r0, r1;
+        r0.x = reduce_wide(h0x, l0x, lc);
+        r0.y = reduce_wide(h0y, l0y, lc);
+        r1.x = reduce_wide(h1x, l1x, lc);
+        r1.y = reduce_wide(h1y, l1y, lc);
+        st2(ctilde + (((size_t)item * 2 + 0) * ext + slot) * g.n + idx, r0);
+        st2(ctilde + (((size_t)item * 2 + 1) * ext + slot) * g.n + idx, r1);
+    }
 }
 
 // =====================================================================================
@@ -523,21 +567,21 @@ const DevConv &Engine::moddown_conv(uint32_t nl) {
 
 template <int N_IN>
 static void launch_baseconv_n(const u64 *in, size_t in_stride, u64 *out, size_t out_stride, const DevConv &cv,
-                              const LimbConst *limb, uint32_t n, uint32_t items, hipStream_t s) {
+                              const LimbConst *limb, uint32_t n, uint32_t items, int prescaled, hipStream_t s) {
     dim3 grid((n + EW_THREADS - 1) / EW_THREADS, items);
-    k_baseconv<N_IN><<<grid, EW_THREADS, 0, s>>>(in, in_stride, out, out_stride, cv, limb, n);
+    k_baseconv<N_IN><<<grid, EW_THREADS, 0, s>>>(in, in_stride, out, out_stride, cv, limb, n, prescaled);
 }
 static void launch_baseconv(const u64 *in, size_t in_stride, u64 *out, size_t out_stride, const DevConv &cv,
-                            const LimbConst *limb, uint32_t n, uint32_t items, hipStream_t s) {
+                            const LimbConst *limb, uint32_t n, uint32_t items, int prescaled, hipStream_t s) {
     switch (cv.n_in) {
-        case 1: launch_baseconv_n<1>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
-        case 2: launch_baseconv_n<2>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
-        case 3: launch_baseconv_n<3>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
-        case 4: launch_baseconv_n<4>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
-        case 5: launch_baseconv_n<5>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
-        case 6: launch_baseconv_n<6>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
-        case 7: launch_baseconv_n<7>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
-        case 8: launch_baseconv_n<8>(in, in_stride, out, out_stride, cv, limb, n, items, s); break;
+        case 1: launch_baseconv_n<1>(in, in_stride, out, out_stride, cv, limb, n, items, prescaled, s); break;
+        case 2: launch_baseconv_n<2>(in, in_stride, out, out_stride, cv, limb, n, items, prescaled, s); break;
+        case 3: launch_baseconv_n<3>(in, in_stride, out, out_stride, cv, limb, n, items, prescaled, s); break;
+        case 4: launch_baseconv_n<4>(in, in_stride, out, out_stride, cv, limb, n, items, prescaled, s); break;
+        case 5: launch_baseconv_n<5>(in, in_stride, out, out_stride, cv, limb, n, items, prescaled, s); break;
+        case 6: launch_baseconv_n<6>(in, in_stride, out, out_stride, cv, limb, n, items, prescaled, s); break;
+        case 7: launch_baseconv_n<7>(in, in_stride, out, out_stride, cv, limb, n, items, prescaled, s); break;
+        case 8: launch_baseconv_n<8>(in, in_stride, out, out_stride, cv, limb, n, items, prescaled, s); break;
         default: throw std::invalid_argument("base conversion fan-in unsupported");
     }
     MK_HIP(hipGetLastError());
@@ -568,15 +612,18 @@ static void launch_col(const NttIo &io, const NttTables &T, uint32_t n_polys, co
     }
 }
 
+static bool row_tail_supported(const NttTables &T) { return fast_log_h(T.log_r2, 1u << T.log_r1) != 0; }
+
 template <bool INV>
-static void launch_row(const NttIo &io, const NttTables &T, uint32_t n_polys, hipStream_t s) {
+static void launch_row(const NttIo &io, const NttTables &T, uint32_t n_polys, const TailArgs &tail, hipStream_t s) {
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t items = n_polys * io.nslots;
     switch (fast_log_h(T.log_r2, r1)) {
-        case 4: k_ntt_row_r<4, INV><<<dim3(r1 / 16, items), NTT_THREADS, 0, s>>>(io, T); break;
-        case 3: k_ntt_row_r<3, INV><<<dim3(r1 / 32, items), NTT_THREADS, 0, s>>>(io, T); break;
-        case 2: k_ntt_row_r<2, INV><<<dim3(r1 / 64, items), NTT_THREADS, 0, s>>>(io, T); break;
+        case 4: k_ntt_row_r<4, INV><<<dim3(r1 / 16, items), NTT_THREADS, 0, s>>>(io, T, tail); break;
+        case 3: k_ntt_row_r<3, INV><<<dim3(r1 / 32, items), NTT_THREADS, 0, s>>>(io, T, tail); break;
+        case 2: k_ntt_row_r<2, INV><<<dim3(r1 / 64, items), NTT_THREADS, 0, s>>>(io, T, tail); break;
         default: {
+            if (tail.enabled) throw std::logic_error("fused tail needs the radix row kernel");
             const uint32_t tile = n < (uint32_t)NTT_TILE ? n : (uint32_t)NTT_TILE;
             k_ntt_row<INV><<<dim3(n / tile, items), NTT_THREADS, (size_t)tile * sizeof(u64), s>>>(io, T);
         }
@@ -591,14 +638,44 @@ static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inve
     second.in = io.out;
     second.in_stride = io.out_stride;
     second.in_slot0 = io.out_slot0;
+    const TailArgs none{};
     if (!inverse) {
         launch_col<false>(io, T, n_polys, nullptr, nullptr, s);
-        launch_row<false>(second, T, n_polys, s);
+        launch_row<false>(second, T, n_polys, none, s);
     } else {
-        launch_row<true>(io, T, n_polys, s);
+        launch_row<true>(io, T, n_polys, none, s);
         launch_col<true>(second, T, n_polys, scale, scale_sh, s);
     }
     MK_HIP(hipGetLastError());
+}
+
+// base conversion fused into the forward column pass of every converted limb (k_conv_col); false when the
+// column pass of this ring size has no radix kernel (the caller then runs k_baseconv + a plain column pass)
+template <int LOG_H>
+static void launch_conv_col_h(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s) {
+    const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
+    const dim3 grid(io.items * tiles * cv.n_out);
+    switch (cv.n_in) {
+        case 1: k_conv_col<LOG_H, 1, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 2: k_conv_col<LOG_H, 2, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 3: k_conv_col<LOG_H, 3, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 4: k_conv_col<LOG_H, 4, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 5: k_conv_col<LOG_H, 5, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 6: k_conv_col<LOG_H, 6, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 7: k_conv_col<LOG_H, 7, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 8: k_conv_col<LOG_H, 8, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        default: throw std::invalid_argument("base conversion fan-in unsupported");
+    }
+}
+static bool launch_conv_col(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s) {
+    switch (fast_log_h(T.log_r1, 1u << T.log_r2)) {
+        case 4: launch_conv_col_h<4>(io, T, cv, s); break;
+        case 3: launch_conv_col_h<3>(io, T, cv, s); break;
+        case 2: launch_conv_col_h<2>(io, T, cv, s); break;
+        default: return false;
+    }
+    MK_HIP(hipGetLastError());
+    return true;
 }
 
 void Engine::ntt_launch(u64 *d, uint32_t n_polys, uint32_t nl, uint32_t ext, bool inverse, const u64 *scale,
@@ -697,56 +774,136 @@ void Engine::rescale(const u64 *in, u64 *out, uint32_t n_ct, uint32_t nl, const 
 
 // ---- hybrid key switching -----------------------------------------------------------
 
+// N^-1 * [(Q_j/q_i)^-1]_{q_i} per Q limb (its digit at this level) and N^-1 * [(P/p_k)^-1]_{p_k} per P limb:
+// the inverse transforms ahead of ModUp / ModDown scale by these, so the conversions take their inputs as is.
+const u64 *Engine::folded_scale(uint32_t nl) {
+    const std::string key = "fold_" + std::to_string(nl);
+    auto it = vec_cache_.find(key);
+    if (it != vec_cache_.end()) return it->second;
+    const uint32_t D = ps_.D;
+    std::vector<u64> v(2 * D, 0);
+    auto put = [&](uint32_t id, u64 hatinv) {
+        const u64 q = ps_.moduli[id];
+        v[id] = h_mulmod(ps_.limb[id].ninv, hatinv, q);
+        v[D + id] = h_shoup(v[id], q);
+    };
+    for (uint32_t part = 0; part < ps_.num_parts(nl); ++part) {
+        BaseConvTable t = ps_.modup_table(nl, part);
+        for (size_t i = 0; i < t.src.size(); ++i) put(t.src[i], t.hatinv[i]);
+    }
+    BaseConvTable t = ps_.moddown_table(nl);
+    for (size_t i = 0; i < t.src.size(); ++i) put(t.src[i], t.hatinv[i]);
+    return limb_vector(key, v);
+}
+
+const u64 *Engine::p_inverse(uint32_t nl) {
+    const std::string key = "pinv_" + std::to_string(nl);
+    auto it = vec_cache_.find(key);
+    if (it != vec_cache_.end()) return it->second;
+    std::vector<u64> pinv(2 * nl);
+    for (uint32_t i = 0; i < nl; ++i) {
+        pinv[i] = ps_.p_inv_mod(i);
+        pinv[nl + i] = h_shoup(pinv[i], ps_.moduli[i]);
+    }
+    return limb_vector(key, pinv);
+}
+
+// EvalKeySwitchPrecomputeCore on `cnt` polynomials c1 (items ct_stride apart): fills the converted limbs of
+// dig[item][part][ext][N] in EVALUATION format; the digits' own limbs are NOT copied (readers take them from c1).
+void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, uint32_t cnt, uint32_t nl) {
+    const uint32_t n = ps_.n, ext = nl + ps_.K, nparts = ps_.num_parts(nl), D = ps_.D;
+    const u64 *fold = folded_scale(nl);
+    // S1: c1 -> COEFFICIENT format, scaled by N^-1 * Qhat_inv
+    NttIo s1{c1, coef, c1_stride, (size_t)nl * n, 0, 0, 0, nl, nl};
+    ntt_passes(s1, tabs_, cnt, true, fold, fold + D, stream_);
+    const size_t dstride = (size_t)nparts * ext * n;
+    bool fused = true;
+    for (uint32_t part = 0; part < nparts && fused; ++part) {
+        // S2+S3a: base conversion fused into the column pass of each complement limb
+        ConvIo io{coef, dig + (size_t)part * ext * n, (size_t)nl * n, dstride, cnt};
+        fused = launch_conv_col(io, tabs_, modup_conv(nl, part), stream_);
+    }
+    if (fused) {
+        // S3b: one row pass over every converted limb of every digit (own limbs skipped)
+        NttIo row{dig, dig, (size_t)ext * n, (size_t)ext * n, 0, 0, 0, ext, nl, nparts, ps_.alpha};
+        launch_row<false>(row, tabs_, cnt * nparts, TailArgs{}, stream_);
+        MK_HIP(hipGetLastError());
+        return;
+    }
+    for (uint32_t part = 0; part < nparts; ++part) {  // ring sizes without a radix column kernel
+        const DevConv &cv = modup_conv(nl, part);
+        const uint32_t lo = part * ps_.alpha, hi = lo + cv.n_in;
+        u64 *d = dig + (size_t)part * ext * n;
+        launch_baseconv(coef, (size_t)nl * n, d, dstride, cv, d_limb_, n, cnt, 1, stream_);
+        if (lo > 0) {
+            NttIo a{d, d, dstride, dstride, 0, 0, 0, lo, nl};
+            ntt_passes(a, tabs_, cnt, false, nullptr, nullptr, stream_);
+        }
+        if (hi < ext) {
+            NttIo b{d, d, dstride, dstride, hi, hi, hi, ext - hi, nl};
+            ntt_passes(b, tabs_, cnt, false, nullptr, nullptr, stream_);
+        }
+    }
+}
+
+// ApproxModDown on `cnt` polynomials til[item][ext][N] -> out[item] (items out_stride apart, nl limbs each);
+// add (optional): ciphertext array whose c0 is added on even items (KeySwitchInPlace: c0 += ...).
+void Engine::moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t out_stride, const u64 *add,
+                          size_t add_stride, uint32_t cnt, uint32_t nl) {
+    const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, D = ps_.D;
+    const u64 *fold = folded_scale(nl), *pinv = p_inverse(nl);
+    NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
+    ntt_passes(s5, tabs_, cnt, true, fold, fold + D, stream_);
+    const DevConv &cv = moddown_conv(nl);
+    ConvIo io{pc, conv, (size_t)K * n, (size_t)nl * n, cnt};
+    EwGeom g{n, nl, ps_.L};
+    if (launch_conv_col(io, tabs_, cv, stream_) && row_tail_supported(tabs_)) {
+        // row pass of the converted limbs with the (ctilde_Q - conv) * P^-1 (+ c0) tail in its copy-out
+        NttIo row{conv, out, (size_t)nl * n, out_stride, 0, 0, 0, nl, nl};
+        TailArgs tail{til, add, pinv, pinv + nl, add_stride, ext, 1};
+        launch_row<false>(row, tabs_, cnt, tail, stream_);
+        MK_HIP(hipGetLastError());
+        return;
+    }
+    launch_baseconv(pc, (size_t)K * n, conv, (size_t)nl * n, cv, d_limb_, n, cnt, 1, stream_);
+    ntt_launch(conv, cnt, nl, nl, false, nullptr, nullptr);
+    k_moddown_tail<<<ew_grid(n, nl, cnt), EW_THREADS, 0, stream_>>>(til, conv, out, g, d_limb_, ext, pinv, pinv + nl,
+                                                                 add, add_stride, out_stride);
+    MK_HIP(hipGetLastError());
+}
+
 void Engine::modup(const u64 *c1, u64 *digits, uint32_t cnt, uint32_t nl) {
     need_device();
     check_nl(nl);
     if (!cnt) return;
     const uint32_t n = ps_.n, ext = nl + ps_.K, nparts = ps_.num_parts(nl);
-    // the digit buffers are also the NTT scratch; the coefficient copy of c1 lives in the arena
     u64 *coef = workspace((size_t)cnt * nl * n);
-    NttIo io{c1, coef, (size_t)nl * n, (size_t)nl * n, 0, 0, 0, nl, nl};
-    ntt_passes(io, tabs_, cnt, true, nullptr, nullptr, stream_);
+    modup_core(c1, (size_t)nl * n, coef, digits, cnt, nl);
+    // the public digit layout carries the own limbs too (EvalKeySwitchPrecomputeCore's partsCtExt)
     const size_t dstride = (size_t)nparts * ext * n;
     for (uint32_t part = 0; part < nparts; ++part) {
-        const DevConv &cv = modup_conv(nl, part);
-        const uint32_t lo = part * ps_.alpha, hi = lo + cv.n_in;
-        u64 *dig = digits + (size_t)part * ext * n;
-        launch_baseconv(coef, (size_t)nl * n, dig, dstride, cv, d_limb_, n, cnt, stream_);
-        if (lo > 0) {
-            NttIo a{dig, dig, dstride, dstride, 0, 0, 0, lo, nl};
-            ntt_passes(a, tabs_, cnt, false, nullptr, nullptr, stream_);
-        }
-        if (hi < ext) {
-            NttIo b{dig, dig, dstride, dstride, hi, hi, hi, ext - hi, nl};
-            ntt_passes(b, tabs_, cnt, false, nullptr, nullptr, stream_);
-        }
-        k_copy_slots<<<ew_grid(n, hi - lo, cnt), EW_THREADS, 0, stream_>>>(c1, (size_t)nl * n, lo, dig, dstride, lo, n);
-        MK_HIP(hipGetLastError());
+        const uint32_t lo = part * ps_.alpha, hi = std::min(nl, lo + ps_.alpha);
+        k_copy_slots<<<ew_grid(n, hi - lo, cnt), EW_THREADS, 0, stream_>>>(c1, (size_t)nl * n, lo,
+                                                                         digits + (size_t)part * ext * n, dstride, lo, n);
     }
+    MK_HIP(hipGetLastError());
 }
 
 void Engine::moddown(const u64 *in, u64 *out, uint32_t cnt, uint32_t nl) {
     need_device();
     check_nl(nl);
     if (!cnt) return;
-    const uint32_t n = ps_.n, K = ps_.K, ext = nl + K;
+    const uint32_t n = ps_.n, K = ps_.K;
     const size_t w_pc = (size_t)cnt * K * n, w_conv = (size_t)cnt * nl * n;
-    u64 *ws = workspace(w_pc + w_conv + 2 * nl);
-    u64 *pc = ws, *conv = ws + w_pc;
-    std::vector<u64> pinv(2 * nl);
-    for (uint32_t i = 0; i < nl; ++i) {
-        pinv[i] = ps_.p_inv_mod(i);
-        pinv[nl + i] = h_shoup(pinv[i], ps_.moduli[i]);
-    }
-    const u64 *d_pinv = limb_vector("pinv_" + std::to_string(nl), pinv);
-    NttIo io{in, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
-    ntt_passes(io, tabs_, cnt, true, nullptr, nullptr, stream_);
-    launch_baseconv(pc, (size_t)K * n, conv, (size_t)nl * n, moddown_conv(nl), d_limb_, n, cnt, stream_);
-    ntt_launch(conv, cnt, nl, nl, false, nullptr, nullptr);
-    EwGeom g{n, nl, ps_.L};
-    k_moddown_tail<<<ew_grid(n, nl, cnt), EW_THREADS, 0, stream_>>>(in, conv, out, g, d_limb_, ext, d_pinv,
-                                                                 d_pinv + nl, nullptr, 0, (size_t)nl * n);
-    MK_HIP(hipGetLastError());
+    u64 *ws = workspace(w_pc + w_conv);
+    moddown_core(in, ws, ws + w_pc, out, (size_t)nl * n, nullptr, 0, cnt, nl);
+}
+
+template <int NPARTS>
+static void launch_inner(const u64 *dig, const u64 *c1, size_t c1_stride, const u64 *evk, u64 *til, EwGeom g,
+                         const LimbConst *limb, uint32_t ext, uint32_t D, uint32_t alpha, uint32_t items, hipStream_t s) {
+    k_inner_product_b<NPARTS><<<dim3((g.n / 2 + EW_THREADS - 1) / EW_THREADS, ext), EW_THREADS, 0, s>>>(
+        dig, c1, c1_stride, evk, til, g, limb, ext, D, alpha, items);
 }
 
 void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t cnt, uint32_t nl) {
@@ -756,47 +913,25 @@ void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t c
     const size_t w_til = (size_t)cnt * 2 * ext * n, w_pc = (size_t)cnt * 2 * K * n, w_conv = (size_t)cnt * 2 * nl * n;
     u64 *ws = workspace(w_coef + w_dig + w_til + w_pc + w_conv);
     u64 *coef = ws, *dig = coef + w_coef, *til = dig + w_dig, *pc = til + w_til, *conv = pc + w_pc;
-    std::vector<u64> pinv(2 * nl);
-    for (uint32_t i = 0; i < nl; ++i) {
-        pinv[i] = ps_.p_inv_mod(i);
-        pinv[nl + i] = h_shoup(pinv[i], ps_.moduli[i]);
-    }
-    const u64 *d_pinv = limb_vector("pinv_" + std::to_string(nl), pinv);
     const u64 *c1 = ct + (size_t)nl * n;  // component 1 of item 0; items are ct_stride apart
 
-    // S1: INTT of c1 (EvalKeySwitchPrecomputeCore: SetFormat(COEFFICIENT))
-    NttIo s1{c1, coef, ct_stride, (size_t)nl * n, 0, 0, 0, nl, nl};
-    ntt_passes(s1, tabs_, cnt, true, nullptr, nullptr, stream_);
-    // S2+S3: per digit ApproxSwitchCRTBasis to the complement basis, NTT, own limbs copied
-    const size_t dstride = (size_t)nparts * ext * n;
-    for (uint32_t part = 0; part < nparts; ++part) {
-        const DevConv &cv = modup_conv(nl, part);
-        const uint32_t lo = part * ps_.alpha, hi = lo + cv.n_in;
-        u64 *d = dig + (size_t)part * ext * n;
-        launch_baseconv(coef, (size_t)nl * n, d, dstride, cv, d_limb_, n, cnt, stream_);
-        if (lo > 0) {
-            NttIo a{d, d, dstride, dstride, 0, 0, 0, lo, nl};
-            ntt_passes(a, tabs_, cnt, false, nullptr, nullptr, stream_);
-        }
-        if (hi < ext) {
-            NttIo b{d, d, dstride, dstride, hi, hi, hi, ext - hi, nl};
-            ntt_passes(b, tabs_, cnt, false, nullptr, nullptr, stream_);
-        }
-        k_copy_slots<<<ew_grid(n, hi - lo, cnt), EW_THREADS, 0, stream_>>>(c1, ct_stride, lo, d, dstride, lo, n);
-        MK_HIP(hipGetLastError());
-    }
-    // S4: inner product with the eval key over Q_l P (EvalFastKeySwitchCoreExt)
+    // S1-S3: ModUp digits of c1 (EvalKeySwitchPrecomputeCore)
+    modup_core(c1, ct_stride, coef, dig, cnt, nl);
+    // S4: inner product with the eval key over Q_l P (EvalFastKeySwitchCoreExt); the eval key stays in
+    // registers across the batch, own limbs come straight from c1
     EwGeom g{n, nl, ps_.L};
-    k_inner_product<<<ew_grid(n, ext, cnt), EW_THREADS, 0, stream_>>>(dig, evk, til, g, d_limb_, ext, nparts, D);
+    switch (nparts) {
+        case 1: launch_inner<1>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
+        case 2: launch_inner<2>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
+        case 3: launch_inner<3>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
+        case 4: launch_inner<4>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
+        case 5: launch_inner<5>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
+        case 6: launch_inner<6>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
+        default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
+    }
     MK_HIP(hipGetLastError());
     // S5: ApproxModDown of both components (2*cnt polynomials of ext limbs), + c0 on component 0
-    NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
-    ntt_passes(s5, tabs_, 2 * cnt, true, nullptr, nullptr, stream_);
-    launch_baseconv(pc, (size_t)K * n, conv, (size_t)nl * n, moddown_conv(nl), d_limb_, n, 2 * cnt, stream_);
-    ntt_launch(conv, 2 * cnt, nl, nl, false, nullptr, nullptr);
-    k_moddown_tail<<<ew_grid(n, nl, 2 * cnt), EW_THREADS, 0, stream_>>>(til, conv, out, g, d_limb_, ext, d_pinv,
-                                                                     d_pinv + nl, ct, ct_stride, (size_t)nl * n);
-    MK_HIP(hipGetLastError());
+    moddown_core(til, pc, conv, out, (size_t)nl * n, ct, ct_stride, 2 * cnt, nl);
 }
 
 void Engine::reencrypt(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl) {

@@ -97,6 +97,11 @@ private:
     void ntt_launch(u64 *d, uint32_t n_polys, uint32_t nl, uint32_t ext, bool inverse, const u64 *scale,
                     const u64 *scale_sh);
     void reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl);
+    const u64 *folded_scale(uint32_t nl);
+    const u64 *p_inverse(uint32_t nl);
+    void modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, uint32_t cnt, uint32_t nl);
+    void moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t out_stride, const u64 *add,
+                      size_t add_stride, uint32_t cnt, uint32_t nl);
 
     ParamSet ps_;
     int device_ = -1;
@@ -106,7 +111,7 @@ private:
     u64 *d_tw_ = nullptr, *d_tw_sh_ = nullptr, *d_itw_ = nullptr, *d_itw_sh_ = nullptr;
     u64 *ws_ = nullptr;
     size_t ws_words_ = 0;
-    uint32_t chunk_ = 4;
+    uint32_t chunk_ = 16;  // ciphertexts per key-switch launch group (MKCKKS_CHUNK overrides)
     std::map<std::pair<uint32_t, uint32_t>, DevConv> modup_cache_;
     std::map<uint32_t, DevConv> moddown_cache_;
     std::map<std::string, u64 *> vec_cache_;

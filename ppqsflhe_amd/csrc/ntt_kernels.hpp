@@ -44,7 +44,17 @@ struct NttIo {
     uint32_t vslot0;               // virtual slot of the first limb (decides the limb id)
     uint32_t nslots;               // limbs per polynomial handled by this launch
     uint32_t nl;                   // #Q limbs of the polynomial (slots >= nl are P limbs)
+    // digit buffers [item][part][ext][N]: polynomial p belongs to digit p % skip_nparts, whose own limbs
+    // [part*skip_alpha, min(nl, (part+1)*skip_alpha)) are not transformed (0 = transform everything)
+    uint32_t skip_nparts = 0, skip_alpha = 0;
 };
+
+MK_D bool ntt_slot_skipped(const NttIo &io, uint32_t poly, uint32_t vslot) {
+    if (!io.skip_nparts) return false;
+    const uint32_t lo = (poly % io.skip_nparts) * io.skip_alpha;
+    const uint32_t hi = lo + io.skip_alpha < io.nl ? lo + io.skip_alpha : io.nl;
+    return vslot >= lo && vslot < hi;
+}
 
 MK_D uint32_t limb_id_of(uint32_t vslot, uint32_t nl, uint32_t L) {
     return vslot < nl ? vslot : L + (vslot - nl);

@@ -88,6 +88,27 @@ struct RowTile {
 
 // ---- kernels -----------------------------------------------------------------------
 
+// Forward column pass, everything after the H input words of this thread (rows j + H k, column c) are
+// in x[]: round A, LDS exchange, round B, store rows H j + k (lazy [0,4q): the row pass finishes).
+template <int LOG_H>
+MK_D void col_forward_finish(u64 (&x)[1 << LOG_H], u64 *lds, const u64 *tw, const u64 *tw_sh, const LimbConst &lc,
+                             int j, int c, u64 *dst_col, uint32_t r2) {
+    using TL = ColTile<LOG_H>;
+    constexpr int H = TL::H;
+    u64 w[H - 1], wp[H - 1];
+    load_round_twiddles<LOG_H>(tw, tw_sh, 1u, w, wp);  // same for every column: scalar loads
+    radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
+#pragma unroll
+    for (int k = 0; k < H; ++k) lds[TL::at(k, j, c)] = x[k];  // row j + H k
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < H; ++k) x[k] = lds[TL::at(j, k, c)];  // row H j + k
+    load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w, wp);
+    radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
+#pragma unroll
+    for (int k = 0; k < H; ++k) dst_col[(size_t)(H * j + k) * r2] = x[k];
+}
+
 // Column pass over R1 = H*H rows: one workgroup = S = 256/H adjacent columns.  Global accesses are
 // S x 8-B row segments (128 B at H = 16); one LDS exchange between the two rounds.
 template <int LOG_H, bool INV>
@@ -97,6 +118,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
     constexpr int H = TL::H, S = TL::S;
     __shared__ u64 lds[TL::WORDS];
     const uint32_t poly = blockIdx.y / io.nslots, sl = blockIdx.y % io.nslots;
+    if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;  // block-uniform
     const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
     const LimbConst lc = T.limb[id];
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2;
@@ -105,22 +127,13 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
     u64 *dst = io.out + (size_t)poly * io.out_stride + (size_t)(io.out_slot0 + sl) * n + blockIdx.x * S + c;
     const u64 *tw = (INV ? T.itw : T.tw) + (size_t)id * n;
     const u64 *tw_sh = (INV ? T.itw_sh : T.tw_sh) + (size_t)id * n;
-    u64 x[H], w[H - 1], wp[H - 1];
+    u64 x[H];
     if (!INV) {
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = src[(size_t)(j + H * k) * r2];
-        load_round_twiddles<LOG_H>(tw, tw_sh, 1u, w, wp);  // same for every column: scalar loads
-        radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
-#pragma unroll
-        for (int k = 0; k < H; ++k) lds[TL::at(k, j, c)] = x[k];  // row j + H k
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(j, k, c)];  // row H j + k
-        load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w, wp);
-        radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
-#pragma unroll
-        for (int k = 0; k < H; ++k) dst[(size_t)(H * j + k) * r2] = x[k];  // lazy [0,4q): the row pass finishes
+        col_forward_finish<LOG_H>(x, lds, tw, tw_sh, lc, j, c, dst, r2);
     } else {
+        u64 w[H - 1], wp[H - 1];
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = src[(size_t)(H * j + k) * r2];
         load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w, wp);
@@ -138,14 +151,75 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
     }
 }
 
+// Approximate base conversion (ApproxSwitchCRTBasis) fused into the forward column pass of the
+// converted limb: the H input words of a thread are computed as  sum_i x_i * [S/s_i]_t  from the N_IN
+// source limbs instead of being loaded.  The sources are COEFFICIENT-format limbs that the preceding
+// inverse transform already multiplied by [(S/s_i)^-1]_{s_i} (folded into its N^-1 scaling).
+// Grid: 1-D, (item, target limb, column tile); the n_out workgroups that share one source tile are made
+// neighbours inside one XCD's queue so the 4 source tiles are fetched from HBM once and then hit in L2.
+struct ConvIo {
+    const u64 *in;      // [items][in_slots][N]
+    u64 *out;           // [items][out_slots][N]
+    size_t in_stride, out_stride;
+    uint32_t items;
+};
+template <int LOG_H, int N_IN, typename CONV>
+__global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T, CONV cv) {
+    using TL = ColTile<LOG_H>;
+    constexpr int H = TL::H, S = TL::S;
+    __shared__ u64 lds[TL::WORDS];
+    const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
+    const uint32_t groups = io.items * tiles;  // source tiles
+    uint32_t grp, jt;
+    if (groups % 8 == 0) {  // XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch)
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / cv.n_out) * 8 + xcd;
+        jt = qidx % cv.n_out;
+    } else {
+        grp = blockIdx.x / cv.n_out;
+        jt = blockIdx.x % cv.n_out;
+    }
+    const uint32_t item = grp / tiles, tile = grp % tiles;
+    const uint32_t id = cv.dst_id[jt];
+    const LimbConst lc = T.limb[id];
+    const int c = threadIdx.x % S, j = threadIdx.x / S;
+    const u64 *src = io.in + (size_t)item * io.in_stride + tile * S + c;
+    u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jt] * n + tile * S + c;
+    u64 hat[N_IN];
+#pragma unroll
+    for (int i = 0; i < N_IN; ++i) hat[i] = cv.hat[i * cv.n_out + jt];
+    u64 x[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        u64 hi = 0, lo = 0;
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i)
+            mac128(hi, lo, src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2], hat[i]);
+        x[k] = reduce_wide(hi, lo, lc);
+    }
+    col_forward_finish<LOG_H>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
+}
+
+// ApproxModDown tail folded into the copy-out of the forward row pass:
+//   out = (ctilde_Q - conv) * P^-1  (+ c0 on component 0)
+struct TailArgs {
+    const u64 *til;      // [polys][ext][N]  key-switch accumulators over Q_l P (component-major per ciphertext)
+    const u64 *add;      // ciphertexts [..][2][nl][N]: c0 is added on even polys; may be null
+    const u64 *pinv, *pinv_sh;  // [nl]
+    size_t add_stride;   // words between ciphertexts in `add`
+    uint32_t ext;        // nl + K
+    uint32_t enabled;
+};
+
 // Row pass over rows of R2 = H*H contiguous words: one workgroup = S consecutive rows (S*R2 contiguous
 // words).  The side that needs per-thread contiguous runs goes through LDS with coalesced 16-B accesses.
 template <int LOG_H, bool INV>
-__global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T) {
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T, TailArgs tail) {
     using TL = RowTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S, R = TL::R;
     __shared__ u64 lds[TL::WORDS];
     const uint32_t poly = blockIdx.y / io.nslots, sl = blockIdx.y % io.nslots;
+    if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;  // block-uniform
     const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
     const LimbConst lc = T.limb[id];
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
@@ -172,12 +246,33 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = canon4(x[k], lc.q, lc.q2);  // own words only
         __syncthreads();
-        for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
-            const int gg = (2 * e) / R, xx = (2 * e) % R;
-            ulong2 v;
-            v.x = lds[TL::at(gg, xx)];
-            v.y = lds[TL::at(gg, xx + 1)];
-            reinterpret_cast<ulong2 *>(dst)[e] = v;
+        if (!tail.enabled) {
+            for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
+                const int gg = (2 * e) / R, xx = (2 * e) % R;
+                ulong2 v;
+                v.x = lds[TL::at(gg, xx)];
+                v.y = lds[TL::at(gg, xx + 1)];
+                reinterpret_cast<ulong2 *>(dst)[e] = v;
+            }
+        } else {
+            const u64 pi = tail.pinv[sl], pi_sh = tail.pinv_sh[sl];
+            const u64 *tq = tail.til + ((size_t)poly * tail.ext + sl) * n + (size_t)row0 * R;
+            const u64 *c0 = (tail.add && (poly & 1) == 0)
+                                ? tail.add + (size_t)(poly >> 1) * tail.add_stride + (size_t)sl * n + (size_t)row0 * R
+                                : nullptr;
+            for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
+                const int gg = (2 * e) / R, xx = (2 * e) % R;
+                const ulong2 t = reinterpret_cast<const ulong2 *>(tq)[e];
+                ulong2 v;
+                v.x = shoup_mul(sub_mod(t.x, lds[TL::at(gg, xx)], lc.q), pi, pi_sh, lc.q);
+                v.y = shoup_mul(sub_mod(t.y, lds[TL::at(gg, xx + 1)], lc.q), pi, pi_sh, lc.q);
+                if (c0) {
+                    const ulong2 a = reinterpret_cast<const ulong2 *>(c0)[e];
+                    v.x = add_mod(v.x, a.x, lc.q);
+                    v.y = add_mod(v.y, a.y, lc.q);
+                }
+                reinterpret_cast<ulong2 *>(dst)[e] = v;
+            }
         }
     } else {
         for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {

@@ -93,11 +93,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row(NttIo io, NttTables T) 
         ulong2 v;
         v.x = lds[2 * e];
         v.y = lds[2 * e + 1];
-        if (!INV) {  // last pass of the forward transform: [0,4q) -> [0,q)
-            v.x = v.x >= lc.q2 ? v.x - lc.q2 : v.x;
-            v.x = v.x >= lc.q ? v.x - lc.q : v.x;
-            v.y = v.y >= lc.q2 ? v.y - lc.q2 : v.y;
-            v.y = v.y >= lc.q ? v.y - lc.q : v.y;
+        if (!INV) {  // last pass of the forward transform: [0,8q) -> [0,q)
+            v.x = canon8(v.x, lc.q, lc.q2);
+            v.y = canon8(v.y, lc.q, lc.q2);
         }
         reinterpret_cast<ulong2 *>(dst)[e] = v;
     }
@@ -268,31 +266,6 @@ __global__ void k_baseconv(const u64 *in, size_t in_stride, u64 *out, size_t out
     }
 }
 
-// EvalFastKeySwitchCoreExt: ctilde[item][k][slot] = sum_j digits[item][j][slot] * evk[j][k][id(slot)]
-__global__ void k_inner_product(const u64 *digits, const u64 *evk, u64 *ctilde, EwGeom g, const LimbConst *limb,
-                                uint32_t ext, uint32_t nparts, uint32_t D) {
-    EW_PROLOGUE(ext)
-    const uint32_t id = limb_id_of(slot, g.nl, g.L);
-    const LimbConst lc = limb[id];
-    u64 h0x = 0, l0x = 0, h0y = 0, l0y = 0, h1x = 0, l1x = 0, h1y = 0, l1y = 0;
-    for (uint32_t j = 0; j < nparts; ++j) {
-        const ulong2 d = ld2(digits + (((size_t)item * nparts + j) * ext + slot) * g.n + idx);
-        const ulong2 b = ld2(evk + (((size_t)j * 2 + 0) * D + id) * g.n + idx);
-        const ulong2 a = ld2(evk + (((size_t)j * 2 + 1) * D + id) * g.n + idx);
-        mac128(h0x, l0x, d.x, b.x);
-        mac128(h0y, l0y, d.y, b.y);
-        mac128(h1x, l1x, d.x, a.x);
-        mac128(h1y, l1y, d.y, a.y);
-    }
-    ulong2 r0, r1;
-    r0.x = reduce_wide(h0x, l0x, lc);
-    r0.y = reduce_wide(h0y, l0y, lc);
-    r1.x = reduce_wide(h1x, l1x, lc);
-    r1.y = reduce_wide(h1y, l1y, lc);
-    st2(ctilde + (((size_t)item * 2 + 0) * ext + slot) * g.n + idx, r0);
-    st2(ctilde + (((size_t)item * 2 + 1) * ext + slot) * g.n + idx, r1);
-}
-
 // EvalFastKeySwitchCoreExt, batch form: one workgroup owns a (limb, coefficient range) and keeps the eval-key
 // words b_j, a_j of all NPARTS digits in registers while it walks the `items` ciphertexts of the batch, so the
 // eval key is streamed from HBM once per launch instead of once per ciphertext.  The digit's own limbs are read
@@ -325,10 +298,17 @@ __global__ void k_inner_product_b(const u64 *digits, const u64 *c1, size_t c1_st
             mac128(h1y, l1y, d.y, a[j].y);
         }
         ulong2 r0, r1;
-        r0.x = reduce_wide(h0x, l0x, lc);
-        r0.y = reduce_wide(h0y, l0y, lc);
-        r1.x = reduce_wide(h1x, l1x, lc);
-        r1.y = reduce_wide(h1y, l1y, lc);
+        if (NPARTS <= 4) {
+            r0.x = reduce_sum4(h0x, l0x, lc);
+            r0.y = reduce_sum4(h0y, l0y, lc);
+            r1.x = reduce_sum4(h1x, l1x, lc);
+            r1.y = reduce_sum4(h1y, l1y, lc);
+        } else {
+            r0.x = reduce_wide(h0x, l0x, lc);
+            r0.y = reduce_wide(h0y, l0y, lc);
+            r1.x = reduce_wide(h1x, l1x, lc);
+            r1.y = reduce_wide(h1y, l1y, lc);
+        }
         st2(ctilde + (((size_t)item * 2 + 0) * ext + slot) * g.n + idx, r0);
         st2(ctilde + (((size_t)item * 2 + 1) * ext + slot) * g.n + idx, r1);
     }
@@ -619,9 +599,9 @@ static void launch_row(const NttIo &io, const NttTables &T, uint32_t n_polys, co
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t items = n_polys * io.nslots;
     switch (fast_log_h(T.log_r2, r1)) {
-        case 4: k_ntt_row_r<4, INV><<<dim3(r1 / 16, items), NTT_THREADS, 0, s>>>(io, T, tail); break;
-        case 3: k_ntt_row_r<3, INV><<<dim3(r1 / 32, items), NTT_THREADS, 0, s>>>(io, T, tail); break;
-        case 2: k_ntt_row_r<2, INV><<<dim3(r1 / 64, items), NTT_THREADS, 0, s>>>(io, T, tail); break;
+        case 4: k_ntt_row_r<4, INV><<<dim3((r1 / 16) * items), NTT_THREADS, 0, s>>>(io, T, tail); break;
+        case 3: k_ntt_row_r<3, INV><<<dim3((r1 / 32) * items), NTT_THREADS, 0, s>>>(io, T, tail); break;
+        case 2: k_ntt_row_r<2, INV><<<dim3((r1 / 64) * items), NTT_THREADS, 0, s>>>(io, T, tail); break;
         default: {
             if (tail.enabled) throw std::logic_error("fused tail needs the radix row kernel");
             const uint32_t tile = n < (uint32_t)NTT_TILE ? n : (uint32_t)NTT_TILE;

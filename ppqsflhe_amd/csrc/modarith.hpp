@@ -57,6 +57,13 @@ MK_HD void mul128(u64 a, u64 b, u64 &hi, u64 &lo) {
 #endif
 }
 
+// x - m when x >= m, else x: the borrow of the subtraction drives the select (no separate compare)
+MK_HD u64 csub(u64 x, u64 m) {
+    unsigned long long t;
+    const bool borrow = __builtin_usubll_overflow(x, m, &t);
+    return borrow ? x : (u64)t;
+}
+
 MK_HD u64 add_mod(u64 a, u64 b, u64 q) {
     u64 s = a + b;
     return s >= q ? s - q : s;
@@ -70,10 +77,7 @@ MK_HD u64 shoup_lazy(u64 a, u64 w, u64 wp, u64 q) {
     return a * w - h * q;
 }
 // canonical result in [0, q)
-MK_HD u64 shoup_mul(u64 a, u64 w, u64 wp, u64 q) {
-    u64 r = shoup_lazy(a, w, wp, q);
-    return r >= q ? r - q : r;
-}
+MK_HD u64 shoup_mul(u64 a, u64 w, u64 wp, u64 q) { return csub(shoup_lazy(a, w, wp, q), q); }
 
 // Barrett reduction of a 128-bit x = hi:lo with x < 2^(k+62) (k = bitlen q) to [0,q).
 // qhat = mulhi64(x >> (k-2), mu), mu = floor(2^(62+k)/q): qhat in {Q-2,Q-1,Q}.
@@ -81,8 +85,7 @@ MK_HD u64 barrett_reduce128(u64 hi, u64 lo, const LimbConst &L) {
     u64 y = (hi << (64 - L.sh)) | (lo >> L.sh);
     u64 qh = mulhi64(y, L.mu);
     u64 r = lo - qh * L.q;
-    r = r >= L.q2 ? r - L.q2 : r;
-    return r >= L.q ? r - L.q : r;
+    return csub(csub(r, L.q2), L.q);
 }
 
 // general a*b mod q for a,b < q (product < q^2 < 2^(2k) <= 2^(k+62))
@@ -91,6 +94,11 @@ MK_HD u64 mul_mod(u64 a, u64 b, const LimbConst &L) {
     mul128(a, b, hi, lo);
     return barrett_reduce128(hi, lo, L);
 }
+
+// A sum of at most 4 products a_i*b_i with a_i < 2^60 and b_i < q is below 2^(k+62), so it fits the
+// Barrett window without the fold of reduce_wide (base conversions with <= 4 source limbs, key-switch
+// inner products with <= 4 digits).
+MK_HD u64 reduce_sum4(u64 hi, u64 lo, const LimbConst &L) { return barrett_reduce128(hi, lo, L); }
 
 // reduce an arbitrary 128-bit accumulator (< 2^124) mod q: fold the high word with
 // 2^64 mod q first so that the Barrett window fits (x' < 2^(k+60) + 2^64).

@@ -60,10 +60,25 @@ MK_D uint32_t limb_id_of(uint32_t vslot, uint32_t nl, uint32_t L) {
     return vslot < nl ? vslot : L + (vslot - nl);
 }
 
-// forward CT butterfly on (x, y) in [0,4q): x' = x + w y, y' = x - w y (lazy)
+// forward CT butterfly: x' = x + w y, y' = x - w y (lazy).  One conditional subtraction of 2q on x keeps
+// every value below 8q when the inputs are below 8q (below 4q when they are below 4q); q < 2^60.
 MK_D void ct_butterfly(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 q2) {
-    u64 u = x >= q2 ? x - q2 : x;
+    u64 u = csub(x, q2);
     u64 v = shoup_lazy(y, w, wp, q);
+    x = u + v;
+    y = u - v + q2;
+}
+// the two halves of the every-other-stage schedule used by the register kernels (values < 8q throughout):
+// "c4": x in [0,8q) is first brought to [0,4q); outputs < 6q.   "nc": x in [0,6q) as is; outputs < 8q.
+MK_D void ct_butterfly_c4(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 q2, u64 q4) {
+    u64 u = csub(x, q4);
+    u64 v = shoup_lazy(y, w, wp, q);
+    x = u + v;
+    y = u - v + q2;
+}
+MK_D void ct_butterfly_nc(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 q2) {
+    u64 v = shoup_lazy(y, w, wp, q);
+    u64 u = x;
     x = u + v;
     y = u - v + q2;
 }
@@ -71,8 +86,11 @@ MK_D void ct_butterfly(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 q2) {
 MK_D void gs_butterfly(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 q2) {
     u64 s = x + y;
     u64 d = x + q2 - y;
-    x = s >= q2 ? s - q2 : s;
+    x = csub(s, q2);
     y = shoup_lazy(d, w, wp, q);
+}
+MK_D u64 canon8(u64 v, u64 q, u64 q2) {  // [0,8q) -> [0,q)
+    return csub(csub(csub(v, q2 + q2), q2), q);
 }
 
 // Transform `nsub` independent sub-NTTs of size 2^log_r held in LDS.

@@ -31,18 +31,22 @@ MK_D void load_round_twiddles(const u64 *__restrict__ tw, const u64 *__restrict_
     }
 }
 
-// log2(H) forward stages on H registers; values stay in [0,4q)
+// log2(H) forward stages on H registers.  Inputs < 8q, outputs < 8q: even stages bring x back below 4q
+// before the butterfly (outputs < 6q), odd stages skip the correction (outputs < 8q) -- half the
+// conditional subtractions of the classic Harvey schedule; 8q < 2^63 since q < 2^60.
 template <int LOG_H>
 MK_D void radix_forward(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], const u64 (&wp)[(1 << LOG_H) - 1],
                         u64 q, u64 q2) {
     constexpr int H = 1 << LOG_H;
+    const u64 q4 = q2 + q2;
 #pragma unroll
     for (int s = 0; s < LOG_H; ++s) {
         const int dist = H >> (s + 1);
 #pragma unroll
         for (int p = 0; p < H / 2; ++p) {
             const int g = p / dist, k0 = g * 2 * dist + (p % dist);
-            ct_butterfly(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wp[(1 << s) - 1 + g], q, q2);
+            if (s % 2 == 0) ct_butterfly_c4(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wp[(1 << s) - 1 + g], q, q2, q4);
+            else ct_butterfly_nc(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wp[(1 << s) - 1 + g], q, q2);
         }
     }
 }
@@ -61,11 +65,6 @@ MK_D void radix_inverse(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], 
             gs_butterfly(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wp[(1 << s) - 1 + g], q, q2);
         }
     }
-}
-
-MK_D u64 canon4(u64 v, u64 q, u64 q2) {  // [0,4q) -> [0,q)
-    v = v >= q2 ? v - q2 : v;
-    return v >= q ? v - q : v;
 }
 
 // ---- LDS layouts -------------------------------------------------------------------
@@ -89,7 +88,7 @@ struct RowTile {
 // ---- kernels -----------------------------------------------------------------------
 
 // Forward column pass, everything after the H input words of this thread (rows j + H k, column c) are
-// in x[]: round A, LDS exchange, round B, store rows H j + k (lazy [0,4q): the row pass finishes).
+// in x[]: round A, LDS exchange, round B, store rows H j + k (lazy [0,8q): the row pass finishes).
 template <int LOG_H>
 MK_D void col_forward_finish(u64 (&x)[1 << LOG_H], u64 *lds, const u64 *tw, const u64 *tw_sh, const LimbConst &lc,
                              int j, int c, u64 *dst_col, uint32_t r2) {
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
 #pragma unroll
         for (int i = 0; i < N_IN; ++i)
             mac128(hi, lo, src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2], hat[i]);
-        x[k] = reduce_wide(hi, lo, lc);
+        x[k] = N_IN <= 4 ? reduce_sum4(hi, lo, lc) : reduce_wide(hi, lo, lc);
     }
     col_forward_finish<LOG_H>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
 }
@@ -218,12 +217,25 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
     using TL = RowTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S, R = TL::R;
     __shared__ u64 lds[TL::WORDS];
-    const uint32_t poly = blockIdx.y / io.nslots, sl = blockIdx.y % io.nslots;
+    // 1-D grid over (limb slot, row tile, polynomial).  All polynomials of one (slot, tile) read the same
+    // 2*S*R-word twiddle tile: they are made consecutive inside ONE XCD's queue (blocks b, b+8, ... share an
+    // XCD under round-robin dispatch) so the tile is fetched over the fabric once and then hits in that L2.
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
+    const uint32_t tiles = r1 / S, groups = tiles * io.nslots, n_polys = gridDim.x / groups;
+    uint32_t grp, poly;
+    if (groups % 8 == 0) {
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / n_polys) * 8 + xcd;
+        poly = qidx % n_polys;
+    } else {
+        grp = blockIdx.x / n_polys;
+        poly = blockIdx.x % n_polys;
+    }
+    const uint32_t sl = grp / tiles;
     if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;  // block-uniform
     const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
     const LimbConst lc = T.limb[id];
-    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
-    const uint32_t row0 = blockIdx.x * S;
+    const uint32_t row0 = (grp % tiles) * S;
     const int g = threadIdx.x / H, j = threadIdx.x % H;
     const u64 *src = io.in + (size_t)poly * io.in_stride + (size_t)(io.in_slot0 + sl) * n + (size_t)row0 * R;
     u64 *dst = io.out + (size_t)poly * io.out_stride + (size_t)(io.out_slot0 + sl) * n + (size_t)row0 * R;
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);
         radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
 #pragma unroll
-        for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = canon4(x[k], lc.q, lc.q2);  // own words only
+        for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = canon8(x[k], lc.q, lc.q2);  // own words only
         __syncthreads();
         if (!tail.enabled) {
             for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {

@@ -42,8 +42,10 @@ def algorithmic_bytes_per_unit(N, L, K, beta, n_clients):
 def cpu_baseline(args, log):
     """The oracle (CPU restatement, OpenMP over limbs like OpenFHE's WITH_OPENMP build) on a bounded sample of
     the same workload: `pre` ciphertexts PRE'd, summed, one rescale*const.  kind = "port"."""
-    from oracle.oracle import OracleContext
-    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    from oracle.oracle import OracleContext, set_threads
+    # the GPU box exposes every host core but one GPU's share is 16; the restatement parallelises over <= 2L limbs
+    threads = int(os.environ.get("OMP_NUM_THREADS", min(os.cpu_count() or 1, 16)))
+    set_threads(threads)
     t0 = time.time()
     o = OracleContext(args.log_n, args.depth, args.scaling_bits, 60, dnum=args.dnum)
     log(f"[cpu] oracle context built in {time.time() - t0:.1f}s, threads={threads}")
@@ -93,6 +95,7 @@ def main():
     import torch
     import torch.distributed as dist
     from ppqsflhe_amd import Context
+    from ppqsflhe_amd.sharding import reduce_partial_sums
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -145,7 +148,7 @@ def main():
         ctx.eval_sum(pre, agg, C, B, L)
         if world > 1:
             # per-GPU partial sums are canonical (< 2^61): an integer sum over <= 8 ranks cannot wrap 2^64
-            dist.reduce_scatter_tensor(shard, agg, op=dist.ReduceOp.SUM)
+            reduce_partial_sums(agg, shard)
             ctx.reduce_mod(shard, Bs, L, world)
         ctx.rescale_mult_const(shard, out, Bs, L, inv_n)
 

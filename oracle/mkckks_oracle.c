@@ -9,6 +9,7 @@
 #include "mkckks_oracle.h"
 
 #include <math.h>
+#include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -307,6 +308,7 @@ void orc_ctx_free(orc_ctx *c) {
     free(c);
 }
 
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 uint32_t orc_ring_dim(const orc_ctx *c) { return c->n; }
 uint32_t orc_num_q(const orc_ctx *c) { return c->L; }
 uint32_t orc_num_p(const orc_ctx *c) { return c->K; }

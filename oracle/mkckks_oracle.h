@@ -50,6 +50,7 @@ orc_ctx *orc_ctx_new(uint32_t log_n, uint32_t mult_depth, uint32_t scaling_bits,
                      uint32_t extra_bits);
 void orc_ctx_free(orc_ctx *c);
 
+void orc_set_threads(int n);               /* OpenMP team size for the per-limb loops */
 uint32_t orc_ring_dim(const orc_ctx *c);
 uint32_t orc_num_q(const orc_ctx *c);     /* L */
 uint32_t orc_num_p(const orc_ctx *c);     /* K */

@@ -67,6 +67,13 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """Cap the OpenMP team of the restatement (bench.py's cpu_baseline states the count it used)."""
+    L = lib()
+    L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_set_threads(int(n))
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 

@@ -57,11 +57,11 @@ MK_HD void mul128(u64 a, u64 b, u64 &hi, u64 &lo) {
 #endif
 }
 
-// x - m when x >= m, else x: the borrow of the subtraction drives the select (no separate compare)
+// x - m when x >= m, else x, for x, m < 2^63: the difference is formed with one 64-bit add of the
+// (wave-uniform) negated constant and its sign selects -- no carry chain, no 64-bit compare.
 MK_HD u64 csub(u64 x, u64 m) {
-    unsigned long long t;
-    const bool borrow = __builtin_usubll_overflow(x, m, &t);
-    return borrow ? x : (u64)t;
+    const u64 t = x + (0 - m);
+    return (int64_t)t < 0 ? x : t;
 }
 
 MK_HD u64 add_mod(u64 a, u64 b, u64 q) {

@@ -1,0 +1,61 @@
+// REkeyGen -- drop-in for client/src/REkeyGen.cpp:
+// `REkeyGen <cc.json> <client_privkey> <peer_pubkey> <rekey_out>` (REkeyGen.cpp:15-25).
+// cc->ReKeyGen(privKey, pubKey) (REkeyGen.cpp:52) -> mkckks_rekeygen.
+#include "hostlib.hpp"
+using namespace mkh;
+
+int main(int argc, char *argv[]) {
+    if (argc != 5) {
+        std::cerr << "Usage: " << argv[0] << " <cc.json> <client_privkey.json> <peer_pubkey.json> <rekey_out.json>" << std::endl;
+        return 1;
+    }
+    const std::string cc_path = argv[1], sk_path = argv[2], pk_path = argv[3], rk_path = argv[4];
+    CcFile cc;
+    try {
+        cc = read_cc(cc_path);
+    } catch (const std::exception &) {
+        std::cerr << "Error loading CryptoContext from " << cc_path << std::endl;
+        return 1;
+    }
+    try {
+        Session s(cc);
+        std::cout << "[ReKeyGen] CryptoContext loaded from " << cc_path << std::endl;
+        const uint32_t N = s.N(), D = s.D(), beta = s.beta();
+        std::vector<uint64_t> sk, pk;
+        std::vector<int8_t> sk_t;
+        if (!read_key_file(sk_path, KIND_SK, N, D, 1, sk, &sk_t)) {
+            std::cerr << "Error loading Client private key from " << sk_path << std::endl;
+            return 1;
+        }
+        std::cout << "[ReKeyGen] Client Private Key loaded from " << sk_path << std::endl;
+        if (!read_key_file(pk_path, KIND_PK, N, D, 2, pk)) {
+            std::cerr << "Error loading Peer public key from " << pk_path << std::endl;
+            return 1;
+        }
+        std::cout << "[ReKeyGen] Peer Public Key loaded from " << pk_path << std::endl;
+        Sampler rng;
+        std::vector<int8_t> u((size_t)beta * N);
+        std::vector<int32_t> e0((size_t)beta * N), e1((size_t)beta * N);
+        rng.ternary(u.data(), u.size());
+        rng.gaussian(e0.data(), e0.size());
+        rng.gaussian(e1.data(), e1.size());
+        uint64_t *d_evk = s.alloc<uint64_t>((size_t)beta * 2 * D * N);
+        Session::check(mkckks_rekeygen(s.ctx(), s.to_device(sk_t.data(), N), s.to_device(pk.data(), pk.size()),
+                                       s.to_device(u.data(), u.size()), s.to_device(e0.data(), e0.size()),
+                                       s.to_device(e1.data(), e1.size()), d_evk));
+        std::vector<uint64_t> evk((size_t)beta * 2 * D * N);
+        s.to_host(evk.data(), d_evk, evk.size());
+        std::cout << "[ReKeyGen] Re-encryption key generated successfully" << std::endl;
+        try {
+            write_key_file(rk_path, KIND_RK, N, D, 2 * beta, evk);
+        } catch (const std::exception &) {
+            std::cerr << "[ReKeyGen] Failed to save re-encryption key to " << rk_path << std::endl;
+            return 1;
+        }
+    } catch (const std::exception &e) {
+        std::cerr << "[ReKeyGen] Re-encryption key generation failed: " << e.what() << std::endl;
+        return 1;
+    }
+    std::cout << "[ReKeyGen] Re-encryption key saved to " << rk_path << std::endl;
+    return 0;
+}

@@ -1,0 +1,95 @@
+// decryptModelWeights -- drop-in for client/src/decryptModelWeights.cpp:
+// `decryptModelWeights <cc_path> <privkey_path> <input_encfile> <output_file>` (:28-38; caller client_fns.sh:100).
+// Decrypt (:81,90,108) -> mkckks_decrypt_batch on the GPU (c0 + c1*s, INTT); CRT interpolation + Decode on the host;
+// mean/std_dev keep slot 0 (SetLength(1), :82-83,91-92); values are concatenated and trimmed to prod(shape) (:100-116).
+#include "hostlib.hpp"
+using namespace mkh;
+
+int main(int argc, char *argv[]) {
+    if (argc != 5) {
+        std::cerr << "Usage: " << argv[0] << " <cc_path> <privkey_path> <input_encfile> <output_file>" << std::endl;
+        return 1;
+    }
+    const std::string cc_path = argv[1], privkey_path = argv[2], input_encfile = argv[3], output_file = argv[4];
+    CcFile cc;
+    try {
+        cc = read_cc(cc_path);
+    } catch (const std::exception &) {
+        std::cerr << "[decrypt] ERROR: Failed to load CryptoContext from " << cc_path << std::endl;
+        return 1;
+    }
+    try {
+        Session s(cc);
+        std::cout << "[decrypt] CryptoContext loaded\n";
+        const uint32_t N = s.N(), D = s.D();
+        std::vector<uint64_t> sk;
+        std::vector<int8_t> sk_t;
+        if (!read_key_file(privkey_path, KIND_SK, N, D, 1, sk, &sk_t)) {
+            std::cerr << "[decrypt] ERROR: Failed to load private key from " << privkey_path << std::endl;
+            return 1;
+        }
+        std::cout << "[decrypt] Private key loaded\n";
+        Json encJson;
+        try {
+            encJson = Json::parse_file(input_encfile);
+        } catch (const std::exception &) {
+            std::cerr << "[decrypt] ERROR: Could not open input file: " << input_encfile << std::endl;
+            return 1;
+        }
+        std::cout << "[decrypt] Encrypted weights loaded\n";
+        const std::vector<CtRef> refs = enumerate_cts(encJson);
+        std::vector<std::vector<double>> decoded(refs.size());
+        if (!refs.empty()) {
+            std::vector<Ciphertext> cts;
+            for (const CtRef &r : refs) cts.push_back(decode_ct(ct_string(encJson, r), N));
+            const uint32_t nl = cts[0].nl;
+            for (const Ciphertext &c : cts)
+                if (c.nl != nl) throw std::runtime_error("ciphertexts of one file must share a level");
+            const size_t words = (size_t)2 * nl * N, B = cts.size();
+            std::vector<uint64_t> flat(B * words);
+            for (size_t i = 0; i < B; ++i) std::memcpy(&flat[i * words], cts[i].data.data(), words * 8);
+            uint64_t *d_m = s.alloc<uint64_t>(B * (size_t)nl * N);
+            Session::check(mkckks_decrypt_batch(s.ctx(), s.to_device(flat.data(), flat.size()),
+                                                s.to_device(sk.data(), sk.size()), d_m, (uint32_t)B, nl));
+            std::vector<uint64_t> m(B * (size_t)nl * N);
+            s.to_host(m.data(), d_m, m.size());
+            for (size_t i = 0; i < B; ++i) {
+                decoded[i].resize(s.slots());
+                s.codec().decode(&m[i * (size_t)nl * N], nl, s.moduli().data(), cts[i].scale, decoded[i].data());
+            }
+        }
+        Json plainJson = Json::object();
+        plainJson["weights_summary"] = Json::array();
+        size_t c = 0;
+        for (const Json &encLayer : encJson.at("weights_summary").a) {
+            Json plainLayer = Json::object();
+            plainLayer["layer"] = encLayer.at("layer");
+            plainLayer["shape"] = encLayer.at("shape");
+            plainLayer["mean"] = decoded[c++][0];
+            plainLayer["std_dev"] = decoded[c++][0];
+            size_t expected = 1;
+            for (const Json &dim : encLayer.at("shape").a) expected *= (size_t)dim.as_int();
+            Json samples = Json::array();
+            std::vector<double> all;
+            for (size_t k = 0; k < encLayer.at("values").size(); ++k) {
+                const std::vector<double> &v = decoded[c++];
+                all.insert(all.end(), v.begin(), v.end());
+            }
+            if (all.size() > expected) all.resize(expected);  // trim the zero padding
+            for (double v : all) samples.push_back(Json(v));
+            plainLayer["values"] = samples;
+            plainJson["weights_summary"].push_back(plainLayer);
+        }
+        try {
+            plainJson.write_file(output_file);
+        } catch (const std::exception &) {
+            std::cerr << "[decrypt] ERROR: Failed to open output file: " << output_file << std::endl;
+            return 1;
+        }
+    } catch (const std::exception &e) {
+        std::cerr << "[decrypt] ERROR: " << e.what() << std::endl;
+        return 1;
+    }
+    std::cout << "[decrypt] Decryption completed successfully. Output: " << output_file << std::endl;
+    return 0;
+}

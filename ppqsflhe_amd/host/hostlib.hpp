@@ -1,0 +1,276 @@
+// hostlib.hpp -- shared plumbing of the CLI hosts: CryptoContext file, key files, ciphertext blobs, the
+// weights_summary envelope, and a Session that owns the device context (C-ABI: include/mkckks.h).
+//
+// What it replaces in the reference (paths relative to /root/reference):
+//   Serial::DeserializeFromFile(cc_path, cc, SerType::JSON)          changeCipherDomain.cpp:32-36 (and every main)
+//   Serial::{De,}Serialize(ct, ss, SerType::BINARY) + Base64          changeCipherDomain.cpp:69-78,
+//                                                                     aggregateEncryptedWeights.cpp:18-30
+//   Serial::{SerializeTo,DeserializeFrom}File(key, SerType::JSON)     keyGen.cpp:41-48, REkeyGen.cpp:37-60
+// Blob formats are this project's own (header + raw limb-major residues): OpenFHE's cereal encodings cannot be
+// tested offline (all ciphertext/key blobs are in .MISSING_LARGE_BLOBS) -- SURVEY.md 8b "Serialization note".
+// A CC.json written by OpenFHE IS accepted: its parameters are read and the moduli re-derived and checked.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mkckks.h"
+#include "base64.hpp"
+#include "codec.hpp"
+#include "json.hpp"
+#include "sampler.hpp"
+
+namespace mkh {
+
+// ------------------------------------------------------------------------------------------------
+// CryptoContext description (what genCC writes and every other program reads)
+// ------------------------------------------------------------------------------------------------
+struct CcFile {
+    mkckks_params p{};
+    uint32_t batch = 0;
+    std::string pre_mode = "INDCPA";
+    std::vector<uint64_t> moduli;  // as listed in the file (Q limbs), for cross-checking
+};
+
+// [upstream] lattice/stdlatticeparms: HEStd_128_classic maximum log2(QP) per ring dimension
+inline uint32_t ring_dim_for_security(uint32_t log_qp) {
+    static const struct { uint32_t n, max_bits; } tbl[] = {{1024, 27}, {2048, 54}, {4096, 109}, {8192, 218},
+                                                           {16384, 438}, {32768, 881}, {65536, 1747}, {131072, 3523}};
+    for (auto &e : tbl)
+        if (log_qp <= e.max_bits) return e.n;
+    throw std::runtime_error("parameters exceed the largest supported ring dimension (2^17)");
+}
+
+inline uint32_t ilog2(uint64_t v) { return 63 - (uint32_t)__builtin_clzll(v); }
+inline uint32_t bit_len(uint64_t v) { return 64 - (uint32_t)__builtin_clzll(v); }
+
+// default number of large digits: [upstream] ComputeNumLargeDigits
+inline uint32_t default_dnum(uint32_t depth) { return depth > 3 ? 3 : (depth > 0 ? 2 : 1); }
+
+inline CcFile read_cc(const std::string &path) {
+    Json j = Json::parse_file(path);
+    CcFile cc;
+    if (j.contains("mkckks_cc")) {
+        const Json &c = j.at("mkckks_cc");
+        cc.p.log_n = (uint32_t)c.at("log_n").as_int();
+        cc.p.mult_depth = (uint32_t)c.at("MultiplicativeDepth").as_int();
+        cc.p.scaling_bits = (uint32_t)c.at("ScalingModSize").as_int();
+        cc.p.first_bits = (uint32_t)c.at("FirstModSize").as_int();
+        cc.p.dnum = (uint32_t)c.at("NumLargeDigits").as_int();
+        cc.p.aux_bits = (uint32_t)c.at("AuxBits").as_int();
+        cc.p.extra_bits = (uint32_t)c.at("ExtraBits").as_int();
+        cc.batch = (uint32_t)c.at("BatchSize").as_int();
+        cc.pre_mode = c.at("PREMode").as_string();
+        for (const Json &m : c.at("moduli").a) cc.moduli.push_back(m.as_u64());
+        return cc;
+    }
+    // OpenFHE cereal JSON (server/storage/CC.json): CryptoParametersCKKSRNS nested three levels deep
+    const Json &d = j.at("value0").at("ptr_wrapper").at("data").at("cc").at("ptr_wrapper").at("data");
+    const Json &rns = d.at("value0");
+    const Json &rlwe = rns.at("value0");
+    const Json &base = rlwe.at("value0");
+    const Json &elp = base.at("elp").at("ptr_wrapper").at("data");
+    const Json &enp = base.at("enp").at("ptr_wrapper").at("data");
+    if (rns.at("ks").as_int() != 2) throw std::runtime_error("only HYBRID key switching (ks=2) is supported");
+    if (rns.at("rs").as_int() != 3) throw std::runtime_error("only FLEXIBLEAUTOEXT scaling (rs=3) is supported");
+    for (const Json &lim : elp.at("p").a)
+        cc.moduli.push_back(lim.at("ptr_wrapper").at("data").at("value0").at("cm").at("v").as_u64());
+    if (cc.moduli.size() < 3) throw std::runtime_error("CC.json: too few RNS limbs");
+    cc.p.log_n = ilog2((uint64_t)elp.at("value0").at("rd").as_int());
+    cc.p.mult_depth = (uint32_t)cc.moduli.size() - 2;
+    cc.p.scaling_bits = (uint32_t)enp.at("m").as_int();
+    cc.p.first_bits = bit_len(cc.moduli[0]);
+    cc.p.dnum = (uint32_t)rns.at("dnum").as_int();
+    cc.p.aux_bits = (uint32_t)rns.at("ab").as_int();
+    cc.p.extra_bits = (uint32_t)rns.at("eb").as_int();
+    cc.batch = (uint32_t)enp.at("bs").as_int();
+    return cc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// binary containers
+// ------------------------------------------------------------------------------------------------
+struct BlobHeader {
+    char magic[4];       // "MKCK"
+    uint32_t version;    // 1
+    uint32_t kind;       // 1 ciphertext, 2 public key, 3 secret key, 4 re-encryption key
+    uint32_t ring_dim;
+    uint32_t limbs;      // ciphertext: nl; keys: D
+    uint32_t parts;      // ciphertext: 2; pk: 2; sk: 1; rekey: 2*beta
+    uint32_t level;      // ciphertext: #dropped limbs
+    uint32_t noise_deg;  // ciphertext: noiseScaleDeg
+    double scale;        // ciphertext: scaling factor
+    uint32_t slots;
+    uint32_t reserved;
+};
+static_assert(sizeof(BlobHeader) == 48, "blob header layout");
+
+enum : uint32_t { KIND_CT = 1, KIND_PK = 2, KIND_SK = 3, KIND_RK = 4 };
+
+struct Ciphertext {
+    uint32_t nl = 0, level = 0, noise_deg = 0, slots = 0;
+    double scale = 0;
+    std::vector<uint64_t> data;  // [2][nl][N]
+};
+
+inline std::string encode_ct(const Ciphertext &ct, uint32_t ring_dim) {
+    BlobHeader h{};
+    std::memcpy(h.magic, "MKCK", 4);
+    h.version = 1; h.kind = KIND_CT; h.ring_dim = ring_dim; h.limbs = ct.nl; h.parts = 2;
+    h.level = ct.level; h.noise_deg = ct.noise_deg; h.scale = ct.scale; h.slots = ct.slots;
+    std::string bin(sizeof h + ct.data.size() * 8, '\0');
+    std::memcpy(&bin[0], &h, sizeof h);
+    std::memcpy(&bin[sizeof h], ct.data.data(), ct.data.size() * 8);
+    return Base64Encode(bin);
+}
+
+inline Ciphertext decode_ct(const std::string &b64, uint32_t ring_dim) {
+    std::string bin = Base64Decode(b64);
+    if (bin.size() < sizeof(BlobHeader)) throw std::runtime_error("ciphertext blob too short");
+    BlobHeader h;
+    std::memcpy(&h, bin.data(), sizeof h);
+    if (std::memcmp(h.magic, "MKCK", 4) || h.version != 1 || h.kind != KIND_CT)
+        throw std::runtime_error("not a mkckks ciphertext blob");
+    if (h.ring_dim != ring_dim || h.parts != 2) throw std::runtime_error("ciphertext does not match the CryptoContext");
+    Ciphertext ct;
+    ct.nl = h.limbs; ct.level = h.level; ct.noise_deg = h.noise_deg; ct.scale = h.scale; ct.slots = h.slots;
+    const size_t words = (size_t)2 * h.limbs * ring_dim;
+    if (bin.size() != sizeof h + words * 8) throw std::runtime_error("ciphertext blob has the wrong size");
+    ct.data.resize(words);
+    std::memcpy(ct.data.data(), bin.data() + sizeof h, words * 8);
+    return ct;
+}
+
+inline void write_key_file(const std::string &path, uint32_t kind, uint32_t ring_dim, uint32_t limbs, uint32_t parts,
+                           const std::vector<uint64_t> &data, const std::vector<int8_t> *ternary = nullptr) {
+    BlobHeader h{};
+    std::memcpy(h.magic, "MKCK", 4);
+    h.version = 1; h.kind = kind; h.ring_dim = ring_dim; h.limbs = limbs; h.parts = parts;
+    h.reserved = ternary ? 1 : 0;
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write " + path);
+    std::fwrite(&h, sizeof h, 1, f);
+    std::fwrite(data.data(), 8, data.size(), f);
+    if (ternary) std::fwrite(ternary->data(), 1, ternary->size(), f);
+    std::fclose(f);
+}
+
+inline bool read_key_file(const std::string &path, uint32_t kind, uint32_t ring_dim, uint32_t limbs, uint32_t parts,
+                          std::vector<uint64_t> &data, std::vector<int8_t> *ternary = nullptr) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    BlobHeader h;
+    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && !std::memcmp(h.magic, "MKCK", 4) && h.version == 1 &&
+              h.kind == kind && h.ring_dim == ring_dim && h.limbs == limbs && h.parts == parts;
+    if (ok) {
+        data.resize((size_t)parts * limbs * ring_dim);
+        ok = std::fread(data.data(), 8, data.size(), f) == data.size();
+    }
+    if (ok && ternary) {
+        ternary->resize(ring_dim);
+        ok = h.reserved == 1 && std::fread(ternary->data(), 1, ring_dim, f) == ring_dim;
+    }
+    std::fclose(f);
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Session: CryptoContext on the device
+// ------------------------------------------------------------------------------------------------
+class Session {
+public:
+    explicit Session(const CcFile &cc) : cc_(cc) {
+        mkckks_params p = cc.p;
+        p.device = 0;
+        if (const char *e = std::getenv("MKCKKS_DEVICE")) p.device = std::atoi(e);
+        check(mkckks_ctx_create(&p, &ctx_));
+        check(mkckks_ctx_info(ctx_, &info_));
+        moduli_.resize(info_.num_q + info_.num_p);
+        check(mkckks_ctx_moduli(ctx_, moduli_.data()));
+        for (size_t i = 0; i < cc.moduli.size() && i < info_.num_q; ++i)
+            if (cc.moduli[i] != moduli_[i])
+                throw std::runtime_error("CryptoContext file lists moduli that differ from the derived ones");
+        codec_.reset(new Codec(info_.ring_dim));
+    }
+    ~Session() {
+        for (void *p : bufs_) mkckks_dev_free(ctx_, p);
+        if (ctx_) mkckks_ctx_destroy(ctx_);
+    }
+    Session(const Session &) = delete;
+    Session &operator=(const Session &) = delete;
+
+    static void check(int rc) {
+        if (rc != MKCKKS_OK) throw std::runtime_error(std::string("mkckks: ") + mkckks_last_error());
+    }
+    mkckks_ctx *ctx() { return ctx_; }
+    uint32_t N() const { return info_.ring_dim; }
+    uint32_t L() const { return info_.num_q; }
+    uint32_t K() const { return info_.num_p; }
+    uint32_t D() const { return info_.num_q + info_.num_p; }
+    uint32_t beta() const { return info_.beta; }
+    uint32_t slots() const { return info_.slots; }
+    uint32_t batch() const { return cc_.batch ? cc_.batch : info_.slots; }
+    const std::vector<uint64_t> &moduli() const { return moduli_; }
+    const Codec &codec() const { return *codec_; }
+    double sf(uint32_t level, bool big) const {
+        double v = 0;
+        check(mkckks_scaling_factor(ctx_, level, big ? 1 : 0, &v));
+        return v;
+    }
+
+    template <typename T>
+    T *alloc(size_t count) {
+        void *p = nullptr;
+        check(mkckks_dev_alloc(ctx_, count * sizeof(T), &p));
+        bufs_.push_back(p);
+        return static_cast<T *>(p);
+    }
+    template <typename T>
+    T *to_device(const T *h, size_t count) {
+        T *d = alloc<T>(count);
+        check(mkckks_upload(ctx_, d, h, count * sizeof(T)));
+        return d;
+    }
+    template <typename T>
+    void to_host(T *h, const T *d, size_t count) { check(mkckks_download(ctx_, h, d, count * sizeof(T))); }
+
+private:
+    CcFile cc_;
+    mkckks_ctx *ctx_ = nullptr;
+    mkckks_info info_{};
+    std::vector<uint64_t> moduli_;
+    std::unique_ptr<Codec> codec_;
+    std::vector<void *> bufs_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// weights_summary envelope helpers: the ciphertext fields of one file in a fixed order
+// ------------------------------------------------------------------------------------------------
+struct CtRef {
+    size_t layer;     // index into weights_summary
+    int field;        // 0 mean, 1 std_dev, 2 values[idx]
+    size_t idx;
+};
+
+inline std::vector<CtRef> enumerate_cts(const Json &file) {
+    std::vector<CtRef> refs;
+    const Json &ws = file.at("weights_summary");
+    for (size_t l = 0; l < ws.size(); ++l) {
+        refs.push_back({l, 0, 0});
+        refs.push_back({l, 1, 0});
+        for (size_t k = 0; k < ws.at(l).at("values").size(); ++k) refs.push_back({l, 2, k});
+    }
+    return refs;
+}
+inline const std::string &ct_string(const Json &file, const CtRef &r) {
+    const Json &lay = file.at("weights_summary").at(r.layer);
+    if (r.field == 0) return lay.at("mean").as_string();
+    if (r.field == 1) return lay.at("std_dev").as_string();
+    return lay.at("values").at(r.idx).as_string();
+}
+
+}  // namespace mkh

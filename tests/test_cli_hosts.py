@@ -158,5 +158,6 @@ def test_full_round_through_the_binaries(tmp_path, golden_dir):
     # wrong key -> garbage, not the mean (sanity that decryption really depends on the domain change)
     ok(run("decryptModelWeights", cc, tmp_path / "sk1", tmp_path / "agg.json", tmp_path / "bad.json"))
     bad = json.load(open(tmp_path / "bad.json"))["weights_summary"][0]
-    v = (W["sample_c1_param_2_values"] + W["sample_c2_param_2_values"]) / 2
+    name = bad["layer"]
+    v = (W[f"sample_c1_{name}_values"] + W[f"sample_c2_{name}_values"]) / 2
     assert np.abs(np.array(bad["values"]) - v).max() > 1.0

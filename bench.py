@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--cts", type=int, default=16, help="ciphertexts per client (multiple of --gpus)")
     ap.add_argument("--cpu-sample", type=int, default=96, help="ciphertexts in the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the clients' PRE batches are spread over (each with its own context/workspace)")
     args = ap.parse_args()
 
     import torch
@@ -118,6 +120,14 @@ def main():
 
     ctx = Context(args.log_n, args.depth, args.scaling_bits, 60, dnum=args.dnum, device=local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # optional extra streams: memory-bound kernels (inner product, sums) of one client's batch overlap the
+    # multiply-bound NTT kernels of another's; every stream has its own context (tables + workspace arena)
+    side = []
+    for _ in range(max(0, args.streams - 1)):
+        st = torch.cuda.Stream(device=dev)
+        c2 = Context(args.log_n, args.depth, args.scaling_bits, 60, dnum=args.dnum, device=local_rank)
+        c2.set_stream(st.cuda_stream)
+        side.append((st, c2))
     N, L, K, D, beta = ctx.N, ctx.L, ctx.K, ctx.D, ctx.beta
     C, B = args.clients, args.cts
     log(f"[bench] N=2^{args.log_n} L={L} K={K} dnum={args.dnum} beta={beta}; {C} clients x {B} ct per GPU, {world} GPU(s)")
@@ -143,8 +153,19 @@ def main():
     inv_n = 1.0 / (C * world)
 
     def step():
-        for c in range(C):
-            ctx.reencrypt(ct_in[c], evk[c], pre[c], B, L)
+        if side:
+            main = torch.cuda.current_stream()
+            for st, _ in side:
+                st.wait_stream(main)
+            lanes = [(None, ctx)] + side
+            for c in range(C):
+                st, cx = lanes[c % len(lanes)]
+                cx.reencrypt(ct_in[c], evk[c], pre[c], B, L)
+            for st, _ in side:
+                main.wait_stream(st)
+        else:
+            for c in range(C):
+                ctx.reencrypt(ct_in[c], evk[c], pre[c], B, L)
         ctx.eval_sum(pre, agg, C, B, L)
         if world > 1:
             # per-GPU partial sums are canonical (< 2^61): an integer sum over <= 8 ranks cannot wrap 2^64
@@ -217,6 +238,8 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     ctx.close()
+    for _, c2 in side:
+        c2.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -113,6 +113,35 @@ MK_HD u64 reduce_wide(u64 hi, u64 lo, const LimbConst &L) {
 // reduce one 64-bit word mod q (q may be much smaller than 2^64)
 MK_HD u64 reduce_word(u64 x, const LimbConst &L) { return barrett_reduce128(0, x, L); }
 
+// ---- column accumulation for sums of products of 60-bit numbers ----------------------------------
+// a = a1*2^30 + a0, b = b1*2^30 + b0 (all four halves < 2^30):  sum_i a_i*b_i = C0 + C1*2^30 + C2*2^60 with
+//   C0 = sum a0*b0, C1 = sum (a0*b1 + a1*b0), C2 = sum a1*b1.
+// Every partial product is < 2^60, so for <= 4 terms the three columns fit 64 bits and each is ONE chain of
+// v_mad_u64_u32 (d = a*b + d) -- no carries, no 128-bit adds.  reduce_cols() reduces the triple mod q.
+struct Cols {
+    u64 c0, c1, c2;
+};
+MK_HD void split30(u64 v, uint32_t &lo, uint32_t &hi) {
+    lo = (uint32_t)v & 0x3FFFFFFFu;
+    hi = (uint32_t)(v >> 30);
+}
+MK_HD void mac_cols(Cols &c, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {
+    c.c0 = (u64)a0 * b0 + c.c0;
+    c.c1 = (u64)a0 * b1 + c.c1;
+    c.c1 = (u64)a1 * b0 + c.c1;
+    c.c2 = (u64)a1 * b1 + c.c2;
+}
+// S = c0 + c1*2^30 + c2*2^60 < 2^(k+62)  ->  S mod q.  The Barrett window floor(S / 2^sh) is assembled from
+// the three columns (under-estimate by <= 2), so qhat in {Q-3..Q} and the remainder is below 4q.
+MK_HD u64 reduce_cols(const Cols &c, const LimbConst &L) {
+    const u64 lo = c.c0 + (c.c1 << 30) + (c.c2 << 60);
+    const int e1 = 30 - (int)L.sh;  // sh in [18,58]
+    const u64 y = (c.c0 >> L.sh) + (e1 >= 0 ? (c.c1 << e1) : (c.c1 >> (-e1))) + (c.c2 << (60 - L.sh));
+    const u64 qh = mulhi64(y, L.mu);
+    const u64 r = lo - qh * L.q;
+    return csub(csub(r, L.q2), L.q);
+}
+
 // 128-bit accumulate acc += a*b
 MK_HD void mac128(u64 &hi, u64 &lo, u64 a, u64 b) {
     u64 ph, pl;

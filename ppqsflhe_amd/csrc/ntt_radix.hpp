@@ -184,17 +184,35 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
     const int c = threadIdx.x % S, j = threadIdx.x / S;
     const u64 *src = io.in + (size_t)item * io.in_stride + tile * S + c;
     u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jt] * n + tile * S + c;
-    u64 hat[N_IN];
-#pragma unroll
-    for (int i = 0; i < N_IN; ++i) hat[i] = cv.hat[i * cv.n_out + jt];
     u64 x[H];
+    if (N_IN <= 4) {
+        // sources and [S/s_i]_t are below 2^60: 30-bit column accumulation, pure v_mad_u64_u32 chains
+        uint32_t h0[N_IN], h1[N_IN];
 #pragma unroll
-    for (int k = 0; k < H; ++k) {
-        u64 hi = 0, lo = 0;
+        for (int i = 0; i < N_IN; ++i) split30(cv.hat[i * cv.n_out + jt], h0[i], h1[i]);
 #pragma unroll
-        for (int i = 0; i < N_IN; ++i)
-            mac128(hi, lo, src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2], hat[i]);
-        x[k] = N_IN <= 4 ? reduce_sum4(hi, lo, lc) : reduce_wide(hi, lo, lc);
+        for (int k = 0; k < H; ++k) {
+            Cols acc{0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < N_IN; ++i) {
+                uint32_t t0, t1;
+                split30(src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2], t0, t1);
+                mac_cols(acc, t0, t1, h0[i], h1[i]);
+            }
+            x[k] = reduce_cols(acc, lc);
+        }
+    } else {
+        u64 hat[N_IN];
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i) hat[i] = cv.hat[i * cv.n_out + jt];
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            u64 hi = 0, lo = 0;
+#pragma unroll
+            for (int i = 0; i < N_IN; ++i)
+                mac128(hi, lo, src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2], hat[i]);
+            x[k] = reduce_wide(hi, lo, lc);
+        }
     }
     col_forward_finish<LOG_H>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
 }

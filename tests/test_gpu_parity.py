@@ -16,6 +16,7 @@ CONFIGS = {
     "c1": (12, 1, 40, 60, 2),         # BASELINE configs[0]: N=2^12, depth 1
     "ref": (14, 2, 40, 60, 2),        # the reference's own CC.json
     "c3": (16, 10, 50, 60, 3),        # BASELINE configs[1..2]: N=2^16, L=12, dnum=3
+    "c5s": (12, 18, 50, 60, 3),       # BASELINE configs[4] limb structure (L=20, alpha=7, K=7) at a small ring
 }
 
 
@@ -236,7 +237,8 @@ def test_lift_ntt_matches_oracle_encode(ctxs, name):
 
 
 @pytest.mark.parametrize("name,nl", [("tiny", 5), ("tiny", 4), ("tiny", 3), ("tiny", 1), ("c1", 3), ("c1", 2),
-                                     ("ref", 4), ("ref", 3), ("c3", 12), ("c3", 11)])
+                                     ("ref", 4), ("ref", 3), ("c3", 12), ("c3", 11), ("c3", 5),
+                                     ("c5s", 20), ("c5s", 15), ("c5s", 8)])
 def test_modup_moddown_reencrypt(ctxs, name, nl):
     g, o = ctxs(name)
     rng = np.random.default_rng(16)
@@ -272,10 +274,23 @@ def test_modup_moddown_reencrypt(ctxs, name, nl):
     assert np.array_equal(d_ct.to_host(), got)
 
 
+def test_empty_batches_are_noops(ctxs):
+    g, _ = ctxs("tiny")
+    d = g.empty((1, 2, g.L, g.N))
+    evk = g.empty((g.beta, 2, g.D, g.N))
+    before = d.upload(np.ones((1, 2, g.L, g.N), dtype=np.uint64)).to_host()
+    g.reencrypt(d, evk, d, 0, g.L)
+    g.eval_add(d, d, d, 0, g.L)
+    g.eval_sum(d, d, 3, 0, g.L)
+    g.ntt_forward(d, 0, g.L)
+    g.sync()
+    assert np.array_equal(d.to_host(), before)
+
+
 def test_reencrypt_batch_larger_than_chunk(ctxs):
     g, o = ctxs("tiny")
     rng = np.random.default_rng(17)
-    B, nl = 11, g.L
+    B, nl = 37, g.L
     ct = rand_ct(rng, g, nl, B)
     evk = rand_polys(rng, g, list(range(g.D)) * (2 * g.beta), 1).reshape(g.beta, 2, g.D, g.N)
     d_out = g.empty((B, 2, nl, g.N))

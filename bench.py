@@ -2,8 +2,8 @@
 """bench.py -- ciphertexts/sec aggregated + PRE at N=2^16, L=12 (BASELINE.json metric).
 
 One step = one pass of the hot path over one batch of synthetic client ciphertexts already resident in HBM:
-    for each of C clients:  reencrypt_batch (hybrid key-switch PRE into the common key domain)   [SURVEY 8a a4]
-    eval_sum over the C clients (coefficient-wise modular add)                                   [a5]
+    for each of C clients:  reencrypt(_accumulate)_batch: hybrid key-switch PRE into the common key
+                            domain, folded coefficient-wise into the running aggregate            [SURVEY 8a a4+a5]
     (N>1 GPUs: RCCL reduce-scatter of the per-GPU partial sums as uint64 + reduce_mod)          [8e]
     rescale_mult_const(1/n_clients_total)  (EvalMult(ct, 1/n): rescale then integer constant)    [a6]
 Unit of work = one client ciphertext PRE'd and folded into the aggregate (92.7 MB algorithmic).
@@ -145,28 +145,29 @@ def main():
 
     ct_in = uniform((C, B), list(range(L)) * 2).view(C, B, 2, L, N)
     evk = uniform((C,), list(range(D)) * (2 * beta)).view(C, beta, 2, D, N)
-    pre = torch.empty_like(ct_in)
+    n_lanes = 1 + len(side)
+    accs = torch.empty(n_lanes, B, 2, L, N, dtype=torch.int64, device=dev)  # one running aggregate per stream
     agg = torch.empty(B, 2, L, N, dtype=torch.int64, device=dev)
     Bs = B // world
     shard = torch.empty(Bs, 2, L, N, dtype=torch.int64, device=dev) if world > 1 else agg
     out = torch.empty(Bs, 2, L - 1, N, dtype=torch.int64, device=dev)
     inv_n = 1.0 / (C * world)
+    lanes = [(None, ctx)] + side
 
     def step():
-        if side:
-            main = torch.cuda.current_stream()
-            for st, _ in side:
-                st.wait_stream(main)
-            lanes = [(None, ctx)] + side
-            for c in range(C):
-                st, cx = lanes[c % len(lanes)]
-                cx.reencrypt(ct_in[c], evk[c], pre[c], B, L)
-            for st, _ in side:
-                main.wait_stream(st)
-        else:
-            for c in range(C):
-                ctx.reencrypt(ct_in[c], evk[c], pre[c], B, L)
-        ctx.eval_sum(pre, agg, C, B, L)
+        main = torch.cuda.current_stream()
+        for st, _ in side:
+            st.wait_stream(main)
+        for c in range(C):
+            lane = c % n_lanes
+            cx = lanes[lane][1]
+            if c < n_lanes:   # first client of the lane starts its aggregate
+                cx.reencrypt(ct_in[c], evk[c], accs[lane], B, L)
+            else:             # PRE folded straight into the running aggregate (no round trip through HBM)
+                cx.reencrypt_accumulate(ct_in[c], evk[c], accs[lane], B, L)
+        for st, _ in side:
+            main.wait_stream(st)
+        ctx.eval_sum(accs, agg, n_lanes, B, L)
         if world > 1:
             # per-GPU partial sums are canonical (< 2^61): an integer sum over <= 8 ranks cannot wrap 2^64
             reduce_partial_sums(agg, shard)
@@ -218,7 +219,7 @@ def main():
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"C3+C4: {C} clients x {B} ct per GPU, N=2^{args.log_n}, L={L}, K={K}, dnum={args.dnum}: "
-                               "reencrypt_batch (hybrid key-switch PRE) -> eval_sum -> "
+                               "reencrypt_accumulate_batch (hybrid key-switch PRE folded into the aggregate) -> "
                                + ("RCCL reduce_scatter(u64 sum)+reduce_mod -> " if world > 1 else "")
                                + "rescale_mult_const(1/n)",
                    "ring_dim": N, "limbs": L, "special_limbs": K, "dnum": args.dnum, "clients_per_gpu": C,

@@ -117,6 +117,11 @@ int mkckks_mult_const_batch(mkckks_ctx *c, uint64_t *d_ct, uint32_t n_ct, uint32
  * ciphertexts have nl <= L limbs; in/out may alias. */
 int mkckks_reencrypt_batch(mkckks_ctx *c, const uint64_t *d_ct, const uint64_t *d_evk, uint64_t *d_out,
                            uint32_t n_ct, uint32_t nl);
+/* the same, folded into a running aggregate: d_acc[b] = d_acc[b] + ReEncrypt(d_ct[b]) coefficient-wise mod q_i
+ * (ReEncrypt at changeCipherDomain.cpp:74 followed by EvalAdd at aggregateEncryptedWeights.cpp:82, without the
+ * round trip of the re-encrypted ciphertext through HBM).  d_acc must not alias d_ct. */
+int mkckks_reencrypt_accumulate_batch(mkckks_ctx *c, const uint64_t *d_ct, const uint64_t *d_evk, uint64_t *d_acc,
+                                      uint32_t n_ct, uint32_t nl);
 /* stages of the above, exposed for parity tests and profiling:
  * KeySwitchHYBRID::EvalKeySwitchPrecomputeCore: c1 u64[n][nl][N] ->
  * digits u64[n][nparts][nl+K][N]; ApproxModDown: u64[n][nl+K][N] -> u64[n][nl][N]. */

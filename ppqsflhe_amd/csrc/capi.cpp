@@ -212,6 +212,13 @@ int mkckks_reencrypt_batch(mkckks_ctx *c, const uint64_t *ct, const uint64_t *ev
         c->eng->reencrypt(ct, evk, out, n_ct, nl);
     });
 }
+int mkckks_reencrypt_accumulate_batch(mkckks_ctx *c, const uint64_t *ct, const uint64_t *evk, uint64_t *acc,
+                                      uint32_t n_ct, uint32_t nl) {
+    return guarded([&] {
+        need(c && ct && evk && acc, "null argument");
+        c->eng->reencrypt(ct, evk, acc, n_ct, nl, true);
+    });
+}
 int mkckks_modup_batch(mkckks_ctx *c, const uint64_t *c1, uint64_t *digits, uint32_t n, uint32_t nl) {
     return guarded([&] {
         need(c && c1 && digits, "null argument");

@@ -214,7 +214,7 @@ __global__ void k_sub_mul(const u64 *in, const u64 *tmp, u64 *out, EwGeom g, con
 // in has ext = nl+K slots per item, conv/out have nl.
 __global__ void k_moddown_tail(const u64 *in, const u64 *conv, u64 *out, EwGeom g, const LimbConst *limb,
                                uint32_t ext, const u64 *pinv, const u64 *pinv_sh, const u64 *add,
-                               size_t add_stride, size_t out_item_stride) {
+                               size_t add_stride, size_t out_item_stride, int accumulate) {
     EW_PROLOGUE(g.nl)
     const u64 q = limb[slot].q;
     const ulong2 x = ld2(in + ((size_t)item * ext + slot) * g.n + idx);
@@ -227,7 +227,13 @@ __global__ void k_moddown_tail(const u64 *in, const u64 *conv, u64 *out, EwGeom 
         r.x = add_mod(r.x, c.x, q);
         r.y = add_mod(r.y, c.y, q);
     }
-    st2(out + (size_t)item * out_item_stride + (size_t)slot * g.n + idx, r);
+    u64 *o = out + (size_t)item * out_item_stride + (size_t)slot * g.n + idx;
+    if (accumulate) {
+        const ulong2 a = ld2(o);
+        r.x = add_mod(r.x, a.x, q);
+        r.y = add_mod(r.y, a.y, q);
+    }
+    st2(o, r);
 }
 
 // copy selected limb slots between strided polynomial arrays
@@ -577,16 +583,18 @@ static int fast_log_h(uint32_t log_r, uint32_t other_extent) {
     return (256u / h) <= other_extent ? (int)(log_r / 2) : 0;
 }
 
+// pack != 0 (inverse radix kernels only): results leave as packed 30-bit halves for k_conv_col
 template <bool INV>
 static void launch_col(const NttIo &io, const NttTables &T, uint32_t n_polys, const u64 *scale, const u64 *scale_sh,
-                       hipStream_t s) {
+                       hipStream_t s, int pack = 0) {
     const uint32_t r1 = 1u << T.log_r1, r2 = 1u << T.log_r2;
     const uint32_t items = n_polys * io.nslots;
     switch (fast_log_h(T.log_r1, r2)) {
-        case 4: k_ntt_col_r<4, INV><<<dim3(r2 / 16, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh); break;
-        case 3: k_ntt_col_r<3, INV><<<dim3(r2 / 32, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh); break;
-        case 2: k_ntt_col_r<2, INV><<<dim3(r2 / 64, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh); break;
+        case 4: k_ntt_col_r<4, INV><<<dim3(r2 / 16, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); break;
+        case 3: k_ntt_col_r<3, INV><<<dim3(r2 / 32, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); break;
+        case 2: k_ntt_col_r<2, INV><<<dim3(r2 / 64, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); break;
         default:
+            if (pack) throw std::logic_error("packed output needs the radix column kernel");
             k_ntt_col<INV><<<dim3(r2 / NTT_COLS, items), NTT_THREADS, (size_t)r1 * NTT_COLS * sizeof(u64), s>>>(
                 io, T, scale, scale_sh);
     }
@@ -612,7 +620,7 @@ static void launch_row(const NttIo &io, const NttTables &T, uint32_t n_polys, co
 
 // two-pass launcher: reads `io.in`, leaves the result in `io.out` (may be the same buffer)
 static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inverse, const u64 *scale,
-                       const u64 *scale_sh, hipStream_t s) {
+                       const u64 *scale_sh, hipStream_t s, int pack = 0) {
     if (n_polys == 0 || io.nslots == 0) return;
     NttIo second = io;  // second pass runs in place on the output
     second.in = io.out;
@@ -624,7 +632,7 @@ static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inve
         launch_row<false>(second, T, n_polys, none, s);
     } else {
         launch_row<true>(io, T, n_polys, none, s);
-        launch_col<true>(second, T, n_polys, scale, scale_sh, s);
+        launch_col<true>(second, T, n_polys, scale, scale_sh, s, pack);
     }
     MK_HIP(hipGetLastError());
 }
@@ -793,15 +801,16 @@ const u64 *Engine::p_inverse(uint32_t nl) {
 void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, uint32_t cnt, uint32_t nl) {
     const uint32_t n = ps_.n, ext = nl + ps_.K, nparts = ps_.num_parts(nl), D = ps_.D;
     const u64 *fold = folded_scale(nl);
+    // the fused conversion kernel exists when the column pass has a radix kernel; it reads packed 30-bit halves
+    bool fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0;
     // S1: c1 -> COEFFICIENT format, scaled by N^-1 * Qhat_inv
     NttIo s1{c1, coef, c1_stride, (size_t)nl * n, 0, 0, 0, nl, nl};
-    ntt_passes(s1, tabs_, cnt, true, fold, fold + D, stream_);
+    ntt_passes(s1, tabs_, cnt, true, fold, fold + D, stream_, fused ? 1 : 0);
     const size_t dstride = (size_t)nparts * ext * n;
-    bool fused = true;
     for (uint32_t part = 0; part < nparts && fused; ++part) {
         // S2+S3a: base conversion fused into the column pass of each complement limb
         ConvIo io{coef, dig + (size_t)part * ext * n, (size_t)nl * n, dstride, cnt};
-        fused = launch_conv_col(io, tabs_, modup_conv(nl, part), stream_);
+        launch_conv_col(io, tabs_, modup_conv(nl, part), stream_);
     }
     if (fused) {
         // S3b: one row pass over every converted limb of every digit (own limbs skipped)
@@ -829,18 +838,20 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
 // ApproxModDown on `cnt` polynomials til[item][ext][N] -> out[item] (items out_stride apart, nl limbs each);
 // add (optional): ciphertext array whose c0 is added on even items (KeySwitchInPlace: c0 += ...).
 void Engine::moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t out_stride, const u64 *add,
-                          size_t add_stride, uint32_t cnt, uint32_t nl) {
+                          size_t add_stride, uint32_t cnt, uint32_t nl, bool accumulate) {
     const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, D = ps_.D;
     const u64 *fold = folded_scale(nl), *pinv = p_inverse(nl);
+    const bool fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0 && row_tail_supported(tabs_);
     NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
-    ntt_passes(s5, tabs_, cnt, true, fold, fold + D, stream_);
+    ntt_passes(s5, tabs_, cnt, true, fold, fold + D, stream_, fused ? 1 : 0);
     const DevConv &cv = moddown_conv(nl);
     ConvIo io{pc, conv, (size_t)K * n, (size_t)nl * n, cnt};
     EwGeom g{n, nl, ps_.L};
-    if (launch_conv_col(io, tabs_, cv, stream_) && row_tail_supported(tabs_)) {
+    if (fused) {
+        launch_conv_col(io, tabs_, cv, stream_);
         // row pass of the converted limbs with the (ctilde_Q - conv) * P^-1 (+ c0) tail in its copy-out
         NttIo row{conv, out, (size_t)nl * n, out_stride, 0, 0, 0, nl, nl};
-        TailArgs tail{til, add, pinv, pinv + nl, add_stride, ext, 1};
+        TailArgs tail{til, add, pinv, pinv + nl, add_stride, ext, 1, accumulate ? 1u : 0u};
         launch_row<false>(row, tabs_, cnt, tail, stream_);
         MK_HIP(hipGetLastError());
         return;
@@ -848,7 +859,7 @@ void Engine::moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t o
     launch_baseconv(pc, (size_t)K * n, conv, (size_t)nl * n, cv, d_limb_, n, cnt, 1, stream_);
     ntt_launch(conv, cnt, nl, nl, false, nullptr, nullptr);
     k_moddown_tail<<<ew_grid(n, nl, cnt), EW_THREADS, 0, stream_>>>(til, conv, out, g, d_limb_, ext, pinv, pinv + nl,
-                                                                 add, add_stride, out_stride);
+                                                                 add, add_stride, out_stride, accumulate ? 1 : 0);
     MK_HIP(hipGetLastError());
 }
 
@@ -876,7 +887,7 @@ void Engine::moddown(const u64 *in, u64 *out, uint32_t cnt, uint32_t nl) {
     const uint32_t n = ps_.n, K = ps_.K;
     const size_t w_pc = (size_t)cnt * K * n, w_conv = (size_t)cnt * nl * n;
     u64 *ws = workspace(w_pc + w_conv);
-    moddown_core(in, ws, ws + w_pc, out, (size_t)nl * n, nullptr, 0, cnt, nl);
+    moddown_core(in, ws, ws + w_pc, out, (size_t)nl * n, nullptr, 0, cnt, nl, false);
 }
 
 template <int NPARTS>
@@ -886,7 +897,7 @@ static void launch_inner(const u64 *dig, const u64 *c1, size_t c1_stride, const 
         dig, c1, c1_stride, evk, til, g, limb, ext, D, alpha, items);
 }
 
-void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t cnt, uint32_t nl) {
+void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t cnt, uint32_t nl, bool accumulate) {
     const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, nparts = ps_.num_parts(nl), D = ps_.D;
     const size_t ct_stride = (size_t)2 * nl * n;
     const size_t w_coef = (size_t)cnt * nl * n, w_dig = (size_t)cnt * nparts * ext * n;
@@ -911,16 +922,17 @@ void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t c
     }
     MK_HIP(hipGetLastError());
     // S5: ApproxModDown of both components (2*cnt polynomials of ext limbs), + c0 on component 0
-    moddown_core(til, pc, conv, out, (size_t)nl * n, ct, ct_stride, 2 * cnt, nl);
+    moddown_core(til, pc, conv, out, (size_t)nl * n, ct, ct_stride, 2 * cnt, nl, accumulate);
 }
 
-void Engine::reencrypt(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl) {
+void Engine::reencrypt(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl, bool accumulate) {
     need_device();
     check_nl(nl);
+    if (accumulate && ct == out) throw std::invalid_argument("accumulating re-encryption cannot run in place");
     const size_t ct_stride = (size_t)2 * nl * ps_.n;
     for (uint32_t done = 0; done < n_ct; done += chunk_) {
         const uint32_t cnt = n_ct - done < chunk_ ? n_ct - done : chunk_;
-        reencrypt_chunk(ct + done * ct_stride, evk, out + done * ct_stride, cnt, nl);
+        reencrypt_chunk(ct + done * ct_stride, evk, out + done * ct_stride, cnt, nl, accumulate);
     }
 }
 

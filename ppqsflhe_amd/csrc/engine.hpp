@@ -73,7 +73,8 @@ public:
 
     void modup(const u64 *c1, u64 *digits, uint32_t n, uint32_t nl);
     void moddown(const u64 *in, u64 *out, uint32_t n, uint32_t nl);
-    void reencrypt(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl);
+    // accumulate: out[b] += ReEncrypt(ct[b]) (coefficient-wise, mod q) -- the fold into a running aggregate
+    void reencrypt(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl, bool accumulate = false);
 
     void keygen(const int8_t *s, const u64 *a, const int32_t *e, u64 *pk, u64 *sk);
     void rekeygen(const int8_t *s_old, const u64 *pk_new, const int8_t *u, const int32_t *e0,
@@ -96,12 +97,12 @@ private:
     const u64 *limb_vector(const std::string &key, const std::vector<u64> &vals);  // cached small device arrays
     void ntt_launch(u64 *d, uint32_t n_polys, uint32_t nl, uint32_t ext, bool inverse, const u64 *scale,
                     const u64 *scale_sh);
-    void reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl);
+    void reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl, bool accumulate);
     const u64 *folded_scale(uint32_t nl);
     const u64 *p_inverse(uint32_t nl);
     void modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, uint32_t cnt, uint32_t nl);
     void moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t out_stride, const u64 *add,
-                      size_t add_stride, uint32_t cnt, uint32_t nl);
+                      size_t add_stride, uint32_t cnt, uint32_t nl, bool accumulate);
 
     ParamSet ps_;
     int device_ = -1;

@@ -133,14 +133,19 @@ MK_HD void mac_cols(Cols &c, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1)
 }
 // S = c0 + c1*2^30 + c2*2^60 < 2^(k+62)  ->  S mod q.  The Barrett window floor(S / 2^sh) is assembled from
 // the three columns (under-estimate by <= 2), so qhat in {Q-3..Q} and the remainder is below 4q.
-MK_HD u64 reduce_cols(const Cols &c, const LimbConst &L) {
+MK_HD u64 reduce_cols_lazy(const Cols &c, const LimbConst &L) {  // result in [0, 4q)
     const u64 lo = c.c0 + (c.c1 << 30) + (c.c2 << 60);
     const int e1 = 30 - (int)L.sh;  // sh in [18,58]
     const u64 y = (c.c0 >> L.sh) + (e1 >= 0 ? (c.c1 << e1) : (c.c1 >> (-e1))) + (c.c2 << (60 - L.sh));
     const u64 qh = mulhi64(y, L.mu);
-    const u64 r = lo - qh * L.q;
-    return csub(csub(r, L.q2), L.q);
+    return lo - qh * L.q;
 }
+MK_HD u64 reduce_cols(const Cols &c, const LimbConst &L) {
+    return csub(csub(reduce_cols_lazy(c, L), L.q2), L.q);
+}
+// a 60-bit word stored as its two 30-bit halves in the two 32-bit halves of a u64 (what split30 would produce)
+MK_HD u64 pack30(u64 v) { return (v & 0x3FFFFFFFull) | ((v >> 30) << 32); }
+MK_HD u64 unpack30(u64 p) { return (p & 0xFFFFFFFFull) | ((p >> 32) << 30); }
 
 // 128-bit accumulate acc += a*b
 MK_HD void mac128(u64 &hi, u64 &lo, u64 a, u64 b) {

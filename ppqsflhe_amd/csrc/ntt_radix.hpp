@@ -112,7 +112,7 @@ MK_D void col_forward_finish(u64 (&x)[1 << LOG_H], u64 *lds, const u64 *tw, cons
 // S x 8-B row segments (128 B at H = 16); one LDS exchange between the two rounds.
 template <int LOG_H, bool INV>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T, const u64 *scale,
-                                                           const u64 *scale_sh) {
+                                                           const u64 *scale_sh, int pack) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
     __shared__ u64 lds[TL::WORDS];
@@ -146,12 +146,15 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
         radix_inverse<LOG_H>(x, w, wp, lc.q, lc.q2);
         const u64 sc = scale ? scale[id] : lc.ninv, sc_sh = scale ? scale_sh[id] : lc.ninv_sh;
 #pragma unroll
-        for (int k = 0; k < H; ++k) dst[(size_t)(j + H * k) * r2] = shoup_mul(x[k], sc, sc_sh, lc.q);
+        for (int k = 0; k < H; ++k) {
+            const u64 v = shoup_mul(x[k], sc, sc_sh, lc.q);
+            dst[(size_t)(j + H * k) * r2] = pack ? pack30(v) : v;  // packed halves feed k_conv_col directly
+        }
     }
 }
 
 // Approximate base conversion (ApproxSwitchCRTBasis) fused into the forward column pass of the
-// converted limb: the H input words of a thread are computed as  sum_i x_i * [S/s_i]_t  from the N_IN
+// converted limb (sources arrive as packed 30-bit halves, see pack30): the H input words of a thread are computed as  sum_i x_i * [S/s_i]_t  from the N_IN
 // source limbs instead of being loaded.  The sources are COEFFICIENT-format limbs that the preceding
 // inverse transform already multiplied by [(S/s_i)^-1]_{s_i} (folded into its N^-1 scaling).
 // Grid: 1-D, (item, target limb, column tile); the n_out workgroups that share one source tile are made
@@ -195,11 +198,10 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
             Cols acc{0, 0, 0};
 #pragma unroll
             for (int i = 0; i < N_IN; ++i) {
-                uint32_t t0, t1;
-                split30(src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2], t0, t1);
-                mac_cols(acc, t0, t1, h0[i], h1[i]);
+                const u64 p = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2];
+                mac_cols(acc, (uint32_t)p, (uint32_t)(p >> 32), h0[i], h1[i]);
             }
-            x[k] = reduce_cols(acc, lc);
+            x[k] = reduce_cols_lazy(acc, lc);  // < 4q: the first butterfly stage accepts < 8q
         }
     } else {
         u64 hat[N_IN];
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
             u64 hi = 0, lo = 0;
 #pragma unroll
             for (int i = 0; i < N_IN; ++i)
-                mac128(hi, lo, src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2], hat[i]);
+                mac128(hi, lo, unpack30(src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2]), hat[i]);
             x[k] = reduce_wide(hi, lo, lc);
         }
     }
@@ -226,6 +228,7 @@ struct TailArgs {
     size_t add_stride;   // words between ciphertexts in `add`
     uint32_t ext;        // nl + K
     uint32_t enabled;
+    uint32_t accumulate; // out += result (running aggregate over clients) instead of out = result
 };
 
 // Row pass over rows of R2 = H*H contiguous words: one workgroup = S consecutive rows (S*R2 contiguous
@@ -298,6 +301,11 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
                 v.y = shoup_mul(sub_mod(t.y, lds[TL::at(gg, xx + 1)], lc.q), pi, pi_sh, lc.q);
                 if (c0) {
                     const ulong2 a = reinterpret_cast<const ulong2 *>(c0)[e];
+                    v.x = add_mod(v.x, a.x, lc.q);
+                    v.y = add_mod(v.y, a.y, lc.q);
+                }
+                if (tail.accumulate) {
+                    const ulong2 a = reinterpret_cast<const ulong2 *>(dst)[e];
                     v.x = add_mod(v.x, a.x, lc.q);
                     v.y = add_mod(v.y, a.y, lc.q);
                 }

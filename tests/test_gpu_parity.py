@@ -274,6 +274,32 @@ def test_modup_moddown_reencrypt(ctxs, name, nl):
     assert np.array_equal(d_ct.to_host(), got)
 
 
+@pytest.mark.parametrize("name,nl", [("tiny", 5), ("ref", 4), ("c3", 12)])
+def test_reencrypt_accumulate(ctxs, name, nl):
+    # ReEncrypt folded into a running aggregate == EvalAdd of the individually re-encrypted ciphertexts
+    g, o = ctxs(name)
+    rng = np.random.default_rng(19)
+    B, C = 2, 3
+    cts = np.stack([rand_ct(rng, g, nl, B) for _ in range(C)])
+    evks = [rand_polys(rng, g, list(range(g.D)) * (2 * g.beta), 1).reshape(g.beta, 2, g.D, g.N) for _ in range(C)]
+    d_acc = g.empty((B, 2, nl, g.N))
+    for c in range(C):
+        d_ct, d_evk = g.to_device(cts[c]), g.to_device(evks[c])
+        if c == 0:
+            g.reencrypt(d_ct, d_evk, d_acc, B, nl)
+        else:
+            g.reencrypt_accumulate(d_ct, d_evk, d_acc, B, nl)
+    got = d_acc.to_host()
+    for b in range(B):
+        acc = o.reencrypt(cts[0, b], evks[0])
+        for c in range(1, C):
+            acc = o.eval_add(acc, o.reencrypt(cts[c, b], evks[c]))
+        assert np.array_equal(got[b], acc)
+    from ppqsflhe_amd import MkckksError
+    with pytest.raises(MkckksError):
+        g.reencrypt_accumulate(d_acc, g.to_device(evks[0]), d_acc, B, nl)  # aliasing is refused
+
+
 def test_empty_batches_are_noops(ctxs):
     g, _ = ctxs("tiny")
     d = g.empty((1, 2, g.L, g.N))

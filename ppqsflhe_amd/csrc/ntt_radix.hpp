@@ -85,6 +85,35 @@ struct RowTile {
     static MK_D int at(int g, int x) { return g * RS + x + (x >> LOG_H); }
 };
 
+// Row-pass round A twiddles through LDS.  In round A the H threads of a row all need the SAME H-1 twiddles
+// (index ((r1 + row) << s) + g), so per-thread global loads fetch 4 distinct words per wave-instruction.  For the
+// S consecutive rows of a tile the stage-s entries are ONE contiguous run of S*2^s words starting at
+// (r1 + row0) << s: the workgroup loads the S*(H-1) words of each table once, coalesced, and every thread then
+// takes its H-1 pairs with broadcast LDS reads.
+template <int LOG_H>
+struct RowTwA {
+    static constexpr int H = 1 << LOG_H, S = 256 / H, WORDS = S * (H - 1);  // per table
+    static MK_D void stage(u64 *ldsw, u64 *ldswp, const u64 *tw, const u64 *tw_sh, uint32_t base0) {
+        for (int e = threadIdx.x; e < WORDS; e += NTT_THREADS) {
+            const int s = 31 - __clz(e / S + 1);
+            const int off = e - S * ((1 << s) - 1);
+            const uint32_t idx = (base0 << s) + (uint32_t)off;
+            ldsw[e] = tw[idx];
+            ldswp[e] = tw_sh[idx];
+        }
+    }
+    static MK_D void fetch(const u64 *ldsw, const u64 *ldswp, int g, u64 (&w)[H - 1], u64 (&wp)[H - 1]) {
+#pragma unroll
+        for (int s = 0; s < LOG_H; ++s)
+#pragma unroll
+            for (int gg = 0; gg < (1 << s); ++gg) {
+                const int e = S * ((1 << s) - 1) + (g << s) + gg;
+                w[(1 << s) - 1 + gg] = ldsw[e];
+                wp[(1 << s) - 1 + gg] = ldswp[e];
+            }
+    }
+};
+
 // ---- kernels -----------------------------------------------------------------------
 
 // Forward column pass, everything after the H input words of this thread (rows j + H k, column c) are
@@ -236,8 +265,10 @@ struct TailArgs {
 template <int LOG_H, bool INV>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T, TailArgs tail) {
     using TL = RowTile<LOG_H>;
+    using TA = RowTwA<LOG_H>;
     constexpr int H = TL::H, S = TL::S, R = TL::R;
-    __shared__ u64 lds[TL::WORDS];
+    __shared__ u64 lds[TL::WORDS + 2 * TA::WORDS];
+    u64 *twa = lds + TL::WORDS, *twa_sh = twa + TA::WORDS;
     // 1-D grid over (limb slot, row tile, polynomial).  All polynomials of one (slot, tile) read the same
     // 2*S*R-word twiddle tile: they are made consecutive inside ONE XCD's queue (blocks b, b+8, ... share an
     // XCD under round-robin dispatch) so the tile is fetched over the fabric once and then hits in that L2.
@@ -267,7 +298,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
     if (!INV) {
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = src[(size_t)g * R + j + H * k];
-        load_round_twiddles<LOG_H>(tw, tw_sh, base, w, wp);
+        TA::stage(twa, twa_sh, tw, tw_sh, r1 + row0);
+        __syncthreads();
+        TA::fetch(twa, twa_sh, g, w, wp);
         radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
@@ -319,6 +352,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
             lds[TL::at(gg, xx)] = v.x;
             lds[TL::at(gg, xx + 1)] = v.y;
         }
+        TA::stage(twa, twa_sh, tw, tw_sh, r1 + row0);  // for the second (broadcast) round
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
@@ -329,7 +363,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, j + H * k)];
-        load_round_twiddles<LOG_H>(tw, tw_sh, base, w, wp);
+        TA::fetch(twa, twa_sh, g, w, wp);
         radix_inverse<LOG_H>(x, w, wp, lc.q, lc.q2);
 #pragma unroll
         for (int k = 0; k < H; ++k) dst[(size_t)g * R + j + H * k] = x[k];  // lazy [0,2q): the column pass scales

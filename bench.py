@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--dnum", type=int, default=3)
     ap.add_argument("--clients", type=int, default=8, help="clients per GPU")
     ap.add_argument("--cts", type=int, default=16, help="ciphertexts per client (multiple of --gpus)")
-    ap.add_argument("--cpu-sample", type=int, default=96, help="ciphertexts in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=384, help="ciphertexts in the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the clients' PRE batches are spread over (each with its own context/workspace)")

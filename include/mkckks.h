@@ -152,6 +152,18 @@ int mkckks_encrypt_batch(mkckks_ctx *c, const uint64_t *d_pk, const uint64_t *d_
  * reduced exactly per limb: coef double[n][N] -> u64[n][nl][N]. */
 int mkckks_lift_ntt_batch(mkckks_ctx *c, const double *d_coef, uint64_t *d_out, uint32_t n, uint32_t nl);
 
+/* ---- cc->MakeCKKSPackedPlaintext(values)  (encryptModelWeights.cpp:82,90,109) --
+ * CKKSPackedEncoding::Encode, full packing: d_vals double[n][N/2] real slot values
+ * (zero padded by the caller) -> inverse canonical embedding (fp64 special FFT), x scale,
+ * round, residues, NTT -> d_pt u64[n][nl][N].  scale: the plaintext's scaling factor
+ * (FLEXIBLEAUTOEXT level 0: mkckks_scaling_factor(ctx, 0, big=1)). */
+int mkckks_encode_batch(mkckks_ctx *c, const double *d_vals, uint64_t *d_pt, uint32_t n, uint32_t nl, double scale);
+/* ---- pt->GetRealPackedValue()  (decryptModelWeights.cpp:83,92,109) ------------
+ * CRT interpolation of d_m u64[n][nl][N] (output of mkckks_decrypt_batch), / scale,
+ * canonical embedding -> d_vals double[n][N/2].  Upstream Decode's noise flooding is
+ * not applied. */
+int mkckks_decode_batch(mkckks_ctx *c, const uint64_t *d_m, double *d_vals, uint32_t n, uint32_t nl, double scale);
+
 /* ---- cc->Decrypt(sk, ct, &pt)  (client/src/decryptModelWeights.cpp:81,90,108)
  * DecryptCore: m = INTT(c0 + c1*s); d_m out u64[n_ct][nl][N] (COEFFICIENT).
  * CRT interpolation + Decode run on the host (codec.hpp). */

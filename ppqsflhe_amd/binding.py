@@ -68,6 +68,8 @@ SYMBOLS = {
     "mkckks_encrypt_batch": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32]),
     "mkckks_lift_ntt_batch": (_int, [_vp, _vp, _vp, _u32, _u32]),
     "mkckks_decrypt_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32]),
+    "mkckks_encode_batch": (_int, [_vp, _vp, _vp, _u32, _u32, _dbl]),
+    "mkckks_decode_batch": (_int, [_vp, _vp, _vp, _u32, _u32, _dbl]),
     "mkckks_reduce_mod_batch": (_int, [_vp, _vp, _u32, _u32, _u32]),
     "mkckks_ctx_twiddles": (_int, [_vp, _u32, _int, _u64p]),
 }
@@ -276,6 +278,12 @@ class Context:
 
     def lift_ntt(self, coef, out, n, nl):
         self._check(self._L.mkckks_lift_ntt_batch(self._h, _ptr(coef), _ptr(out), n, nl))
+
+    def encode(self, vals, pt, n, nl, scale):
+        self._check(self._L.mkckks_encode_batch(self._h, _ptr(vals), _ptr(pt), n, nl, float(scale)))
+
+    def decode(self, m, vals, n, nl, scale):
+        self._check(self._L.mkckks_decode_batch(self._h, _ptr(m), _ptr(vals), n, nl, float(scale)))
 
     def decrypt(self, ct, sk, m, n_ct, nl):
         self._check(self._L.mkckks_decrypt_batch(self._h, _ptr(ct), _ptr(sk), _ptr(m), n_ct, nl))

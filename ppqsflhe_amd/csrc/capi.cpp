@@ -258,6 +258,20 @@ int mkckks_lift_ntt_batch(mkckks_ctx *c, const double *coef, uint64_t *out, uint
         c->eng->lift_ntt(coef, out, n, nl);
     });
 }
+int mkckks_encode_batch(mkckks_ctx *c, const double *vals, uint64_t *pt, uint32_t n, uint32_t nl, double scale) {
+    return guarded([&] {
+        need(c && vals && pt, "null argument");
+        need(scale > 0, "scale must be positive");
+        c->eng->encode(vals, pt, n, nl, scale);
+    });
+}
+int mkckks_decode_batch(mkckks_ctx *c, const uint64_t *m, double *vals, uint32_t n, uint32_t nl, double scale) {
+    return guarded([&] {
+        need(c && m && vals, "null argument");
+        need(scale > 0, "scale must be positive");
+        c->eng->decode(m, vals, n, nl, scale);
+    });
+}
 int mkckks_decrypt_batch(mkckks_ctx *c, const uint64_t *ct, const uint64_t *sk, uint64_t *m, uint32_t n_ct,
                          uint32_t nl) {
     return guarded([&] {

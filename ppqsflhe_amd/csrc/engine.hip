@@ -14,7 +14,9 @@
 // workgroup (blockIdx.y), so all per-limb constants sit in SGPRs.
 #include "engine.hpp"
 #include "ntt_radix.hpp"
+#include "codec_kernels.hpp"
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -435,6 +437,22 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
         MK_HIP(hipMemcpy(d_itw_ + (size_t)i * n, w.data(), n * sizeof(u64), hipMemcpyHostToDevice));
         MK_HIP(hipMemcpy(d_itw_sh_ + (size_t)i * n, wsh.data(), n * sizeof(u64), hipMemcpyHostToDevice));
     }
+    {   // encoding tables: rotation group 5^j mod 2N and the 2N-th roots of unity (fp64, computed on the host)
+        const uint32_t slots = n / 2, M = 2 * n;
+        std::vector<uint32_t> rot(slots);
+        uint64_t pw = 1;
+        for (uint32_t j = 0; j < slots; ++j) { rot[j] = (uint32_t)pw; pw = pw * 5 % M; }
+        std::vector<double2> ksi(M + 1);
+        const double pi = std::acos(-1.0);
+        for (uint32_t k = 0; k <= M; ++k) {
+            const double ang = 2.0 * pi * (double)k / (double)M;
+            ksi[k] = double2{std::cos(ang), std::sin(ang)};
+        }
+        MK_HIP(hipMalloc(&d_rot_, slots * sizeof(uint32_t)));
+        MK_HIP(hipMalloc(&d_ksi_, (M + 1) * sizeof(double2)));
+        MK_HIP(hipMemcpy(d_rot_, rot.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice));
+        MK_HIP(hipMemcpy(d_ksi_, ksi.data(), (M + 1) * sizeof(double2), hipMemcpyHostToDevice));
+    }
     tabs_.limb = d_limb_;
     tabs_.tw = d_tw_; tabs_.tw_sh = d_tw_sh_; tabs_.itw = d_itw_; tabs_.itw_sh = d_itw_sh_;
     tabs_.log_n = ps_.log_n;
@@ -450,7 +468,8 @@ Engine::~Engine() {
     if (device_ < 0) return;
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
-    for (void *p : {(void *)d_limb_, (void *)d_tw_, (void *)d_tw_sh_, (void *)d_itw_, (void *)d_itw_sh_, (void *)ws_})
+    for (void *p : {(void *)d_limb_, (void *)d_tw_, (void *)d_tw_sh_, (void *)d_itw_, (void *)d_itw_sh_, (void *)ws_,
+                    (void *)d_rot_, (void *)d_ksi_})
         if (p) (void)hipFree(p);
     for (void *p : owned_) (void)hipFree(p);
 }
@@ -1034,6 +1053,56 @@ void Engine::decrypt(const u64 *ct, const u64 *sk, u64 *m, uint32_t n_ct, uint32
     k_fma<<<ew_grid(n, nl, n_ct), EW_THREADS, 0, stream_>>>(c1, s, c0, none, nullptr, 0, m, poly, 0, g, d_limb_, nl);
     MK_HIP(hipGetLastError());
     ntt_launch(m, n_ct, nl, nl, true, nullptr, nullptr);
+}
+
+// ---- CKKS encode / decode (fp64 canonical embedding on the device) ---------------------------------
+
+void Engine::encode(const double *vals, u64 *pt, uint32_t cnt, uint32_t nl, double scale) {
+    need_device();
+    check_nl(nl);
+    if (!cnt) return;
+    const uint32_t n = ps_.n, slots = n / 2;
+    CodecTables t{d_rot_, reinterpret_cast<const double2 *>(d_ksi_), slots, ps_.log_n - 1, 2 * n};
+    // arena: complex work array [cnt][slots] then coefficient doubles [cnt][N] (both 16*slots bytes per item)
+    u64 *ws = workspace((size_t)cnt * n * 2 + (size_t)cnt * n);
+    double2 *v = reinterpret_cast<double2 *>(ws);
+    double *coef = reinterpret_cast<double *>(ws + (size_t)cnt * n * 2);
+    const dim3 gs((slots + 255) / 256, cnt), gh((slots / 2 + 255) / 256, cnt);
+    k_codec_load<<<gs, 256, 0, stream_>>>(vals, v, slots);
+    for (uint32_t len = slots; len >= 2; len >>= 1) k_fft_special_inv_stage<<<gh, 256, 0, stream_>>>(v, t, len);
+    k_codec_to_coef<<<gs, 256, 0, stream_>>>(v, coef, t, scale);
+    MK_HIP(hipGetLastError());
+    EwGeom g{n, nl, ps_.L};
+    k_lift<double><<<ew_grid(n, nl, cnt), EW_THREADS, 0, stream_>>>(coef, pt, g, d_limb_, nl);
+    MK_HIP(hipGetLastError());
+    ntt_launch(pt, cnt, nl, nl, false, nullptr, nullptr);
+}
+
+void Engine::decode(const u64 *m, double *vals, uint32_t cnt, uint32_t nl, double scale) {
+    need_device();
+    check_nl(nl);
+    if (!cnt) return;
+    if (nl > (uint32_t)CRT_MAX_LIMBS) throw std::invalid_argument("decode supports at most 32 limbs");
+    const uint32_t n = ps_.n, slots = n / 2;
+    CodecTables t{d_rot_, reinterpret_cast<const double2 *>(d_ksi_), slots, ps_.log_n - 1, 2 * n};
+    // Garner constants for the first nl limbs: inv[a] = (q_0..q_{a-1})^-1 mod q_a, G[a][k] = q_k mod q_a
+    std::vector<u64> gar((size_t)nl + (size_t)nl * nl, 0);
+    for (uint32_t a = 1; a < nl; ++a) {
+        const u64 qa = ps_.moduli[a];
+        u64 prod = 1;
+        for (uint32_t k = 0; k < a; ++k) {
+            gar[nl + (size_t)a * nl + k] = ps_.moduli[k] % qa;
+            prod = h_mulmod(prod, ps_.moduli[k] % qa, qa);
+        }
+        gar[a] = h_invmod(prod, qa);
+    }
+    const u64 *d_gar = limb_vector("garner_" + std::to_string(nl), gar);
+    double2 *v = reinterpret_cast<double2 *>(workspace((size_t)cnt * n * 2));
+    const dim3 gs((slots + 255) / 256, cnt), gh((slots / 2 + 255) / 256, cnt);
+    k_crt_to_complex<<<gs, 256, 0, stream_>>>(m, v, t, d_limb_, d_gar, nl, scale);
+    for (uint32_t len = 2; len <= slots; len <<= 1) k_fft_special_stage<<<gh, 256, 0, stream_>>>(v, t, len);
+    k_codec_store_real<<<gs, 256, 0, stream_>>>(v, vals, slots);
+    MK_HIP(hipGetLastError());
 }
 
 void Engine::host_twiddles(uint32_t limb, bool inverse, std::vector<u64> &out) const {

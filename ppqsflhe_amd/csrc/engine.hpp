@@ -83,6 +83,9 @@ public:
                  u64 *ct, uint32_t n_ct, uint32_t nl);
     void lift_ntt(const double *coef, u64 *out, uint32_t n, uint32_t nl);
     void decrypt(const u64 *ct, const u64 *sk, u64 *m, uint32_t n_ct, uint32_t nl);
+    // CKKS canonical embedding on the device: vals [n][N/2] reals <-> plaintexts / decrypted polynomials
+    void encode(const double *vals, u64 *pt, uint32_t n, uint32_t nl, double scale);
+    void decode(const u64 *m, double *vals, uint32_t n, uint32_t nl, double scale);
 
     void host_twiddles(uint32_t limb, bool inverse, std::vector<u64> &out) const;
 
@@ -110,6 +113,8 @@ private:
     NttTables tabs_{};
     LimbConst *d_limb_ = nullptr;
     u64 *d_tw_ = nullptr, *d_tw_sh_ = nullptr, *d_itw_ = nullptr, *d_itw_sh_ = nullptr;
+    uint32_t *d_rot_ = nullptr;
+    void *d_ksi_ = nullptr;
     u64 *ws_ = nullptr;
     size_t ws_words_ = 0;
     uint32_t chunk_ = 16;  // ciphertexts per key-switch launch group (MKCKKS_CHUNK overrides)

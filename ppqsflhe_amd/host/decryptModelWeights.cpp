@@ -1,6 +1,6 @@
 // decryptModelWeights -- drop-in for client/src/decryptModelWeights.cpp:
 // `decryptModelWeights <cc_path> <privkey_path> <input_encfile> <output_file>` (:28-38; caller client_fns.sh:100).
-// Decrypt (:81,90,108) -> mkckks_decrypt_batch on the GPU (c0 + c1*s, INTT); CRT interpolation + Decode on the host;
+// Decrypt (:81,90,108) -> mkckks_decrypt_batch (c0 + c1*s, INTT) + mkckks_decode_batch (CRT interpolation, embedding);
 // mean/std_dev keep slot 0 (SetLength(1), :82-83,91-92); values are concatenated and trimmed to prod(shape) (:100-116).
 #include "hostlib.hpp"
 using namespace mkh;
@@ -51,12 +51,14 @@ int main(int argc, char *argv[]) {
             uint64_t *d_m = s.alloc<uint64_t>(B * (size_t)nl * N);
             Session::check(mkckks_decrypt_batch(s.ctx(), s.to_device(flat.data(), flat.size()),
                                                 s.to_device(sk.data(), sk.size()), d_m, (uint32_t)B, nl));
-            std::vector<uint64_t> m(B * (size_t)nl * N);
-            s.to_host(m.data(), d_m, m.size());
-            for (size_t i = 0; i < B; ++i) {
-                decoded[i].resize(s.slots());
-                s.codec().decode(&m[i * (size_t)nl * N], nl, s.moduli().data(), cts[i].scale, decoded[i].data());
-            }
+            for (const Ciphertext &c : cts)
+                if (c.scale != cts[0].scale) throw std::runtime_error("ciphertexts of one file must share a scaling factor");
+            const size_t slots = s.slots();
+            double *d_vals = s.alloc<double>(B * slots);
+            Session::check(mkckks_decode_batch(s.ctx(), d_m, d_vals, (uint32_t)B, nl, cts[0].scale));
+            std::vector<double> vals(B * slots);
+            s.to_host(vals.data(), d_vals, vals.size());
+            for (size_t i = 0; i < B; ++i) decoded[i].assign(vals.begin() + i * slots, vals.begin() + (i + 1) * slots);
         }
         Json plainJson = Json::object();
         plainJson["weights_summary"] = Json::array();

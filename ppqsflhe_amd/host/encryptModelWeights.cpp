@@ -2,7 +2,8 @@
 // `encryptModelWeights <cc_path> <pubkey_path> <input_weights> <output_encfile>` (:19-29).
 // Per layer: {mean}, {std_dev} and the values in chunks of batchSize (zero padded, :100-107) are packed with
 // MakeCKKSPackedPlaintext and encrypted (:82-83,90-91,109-110); layers named "optimizer/..." are skipped (:71-74).
-// Here all plaintexts of the file are encoded on the host, then lifted + encrypted in ONE batched GPU call.
+// Here all plaintexts of the file are encoded (mkckks_encode_batch) and encrypted (mkckks_encrypt_batch) on the GPU in
+// one batch each.
 #include "hostlib.hpp"
 using namespace mkh;
 
@@ -72,8 +73,9 @@ int main(int argc, char *argv[]) {
         const size_t n_ct = plains.size();
         // Encode: FLEXIBLEAUTOEXT level-0 plaintexts carry the big scaling factor sf[0]*sf[1], noiseScaleDeg 2
         const double scale = s.sf(0, true);
-        std::vector<double> coef(n_ct * N);
-        for (size_t c = 0; c < n_ct; ++c) s.codec().encode(plains[c].data(), plains[c].size(), scale, &coef[c * N]);
+        const size_t slots = s.slots();
+        std::vector<double> slot_vals(n_ct * slots, 0.0);  // zero padded to N/2 slots
+        for (size_t c = 0; c < n_ct; ++c) std::copy(plains[c].begin(), plains[c].end(), slot_vals.begin() + c * slots);
         Sampler rng;
         std::vector<int8_t> v(n_ct * N);
         std::vector<int32_t> e0(n_ct * N), e1(n_ct * N);
@@ -81,7 +83,7 @@ int main(int argc, char *argv[]) {
         rng.gaussian(e0.data(), e0.size());
         rng.gaussian(e1.data(), e1.size());
         uint64_t *d_pt = s.alloc<uint64_t>(n_ct * L * N), *d_ct = s.alloc<uint64_t>(n_ct * 2 * L * N);
-        Session::check(mkckks_lift_ntt_batch(s.ctx(), s.to_device(coef.data(), coef.size()), d_pt, (uint32_t)n_ct, L));
+        Session::check(mkckks_encode_batch(s.ctx(), s.to_device(slot_vals.data(), slot_vals.size()), d_pt, (uint32_t)n_ct, L, scale));
         Session::check(mkckks_encrypt_batch(s.ctx(), s.to_device(pk.data(), pk.size()), d_pt, s.to_device(v.data(), v.size()),
                                             s.to_device(e0.data(), e0.size()), s.to_device(e1.data(), e1.size()), d_ct,
                                             (uint32_t)n_ct, L));

@@ -20,7 +20,6 @@
 
 #include "../../include/mkckks.h"
 #include "base64.hpp"
-#include "codec.hpp"
 #include "json.hpp"
 #include "sampler.hpp"
 
@@ -194,7 +193,6 @@ public:
         for (size_t i = 0; i < cc.moduli.size() && i < info_.num_q; ++i)
             if (cc.moduli[i] != moduli_[i])
                 throw std::runtime_error("CryptoContext file lists moduli that differ from the derived ones");
-        codec_.reset(new Codec(info_.ring_dim));
     }
     ~Session() {
         for (void *p : bufs_) mkckks_dev_free(ctx_, p);
@@ -215,7 +213,6 @@ public:
     uint32_t slots() const { return info_.slots; }
     uint32_t batch() const { return cc_.batch ? cc_.batch : info_.slots; }
     const std::vector<uint64_t> &moduli() const { return moduli_; }
-    const Codec &codec() const { return *codec_; }
     double sf(uint32_t level, bool big) const {
         double v = 0;
         check(mkckks_scaling_factor(ctx_, level, big ? 1 : 0, &v));
@@ -243,7 +240,6 @@ private:
     mkckks_ctx *ctx_ = nullptr;
     mkckks_info info_{};
     std::vector<uint64_t> moduli_;
-    std::unique_ptr<Codec> codec_;
     std::vector<void *> bufs_;
 };
 

@@ -236,6 +236,51 @@ def test_lift_ntt_matches_oracle_encode(ctxs, name):
             assert np.array_equal(got[b, l], o.ntt_fwd(l, res))
 
 
+@pytest.mark.parametrize("name", ["tiny", "ref", "c3"])
+def test_encode_decode_on_device(ctxs, name):
+    """Encode / Decode (fp64 canonical embedding + CRT interpolation on the GPU) vs the oracle's host versions.
+    Floating point: coefficients are ~scale * 2^-4 with a 53-bit mantissa, so two correctly rounded FFTs may differ by
+    scale * 2^-50 in a coefficient (a few units at scale 2^60); decoded values must agree far below the scheme's
+    precision (tolerance 2^-40 relative to the value range)."""
+    g, o = ctxs(name)
+    rng = np.random.default_rng(22)
+    N, L, slots = g.N, g.L, g.N // 2
+    B = 2
+    vals = rng.uniform(-0.3, 0.3, size=(B, slots))
+    vals[1, 1:] = 0.0  # the {mean} plaintext shape: one value, zero padding
+    scale = o.sf_big(0)
+    d_pt = g.empty((B, L, N))
+    g.encode(g.to_device(vals), d_pt, B, L, scale)
+    pt = d_pt.to_host()
+    for b in range(B):
+        ref = o.encode(vals[b], scale, L)
+        for l in (0, 1, L - 1):
+            q = int(g.moduli[l])
+            d = (o.ntt_inv(l, pt[b, l]).astype(object) - o.ntt_inv(l, ref[l]).astype(object)) % q
+            d = np.array([int(x) if x <= q // 2 else int(x) - q for x in d])
+            assert np.abs(d).max() <= scale * 2.0 ** -50 + 1, (name, b, l, np.abs(d).max())
+    # decode: CRT + embedding of the exact plaintext polynomial (coefficient form of the oracle's encoding)
+    nl = max(2, L - 1)
+    m = np.stack([np.stack([o.ntt_inv(l, o.encode(vals[b], 2.0 ** 45, nl)[l]) for l in range(nl)]) for b in range(B)])
+    d_vals = g.empty((B, slots), dtype=np.float64)
+    g.decode(g.to_device(m), d_vals, B, nl, 2.0 ** 45)
+    got = d_vals.to_host()
+    assert np.abs(got - vals).max() < 2.0 ** -35  # encoding rounding at scale 2^45 (~sqrt(N) * 2^-46), not a GPU error
+    # round trip entirely on the device at the real scale, through decrypt of a trivial encryption (c1 = 0)
+    ct = np.zeros((B, 2, L, N), dtype=np.uint64)
+    ct[:, 0] = pt
+    d_m = g.empty((B, L, N))
+    g.decrypt(g.to_device(ct), g.to_device(np.zeros((g.D, N), dtype=np.uint64)), d_m, B, L)
+    g.decode(d_m, d_vals, B, L, scale)
+    assert np.abs(d_vals.to_host() - vals).max() < 2.0 ** -40
+    # agreement with the oracle's decoder on a noisy decrypted polynomial
+    s_t = sample_ternary(rng, N)
+    pk, sk = o.keygen(s_t, sample_uniform(rng, o.moduli, N), sample_gauss(rng, N))
+    c = o.encrypt(pk, o.encode(vals[0], scale, L), sample_ternary(rng, N), sample_gauss(rng, N), sample_gauss(rng, N))
+    g.decode(g.to_device(o.decrypt_core(c, sk)[None]), d_vals.view(0, (1, slots)), 1, L, scale)
+    assert np.abs(d_vals.to_host()[0] - o.decrypt_decode(c, sk, scale)).max() < 2.0 ** -40
+
+
 @pytest.mark.parametrize("name,nl", [("tiny", 5), ("tiny", 4), ("tiny", 3), ("tiny", 1), ("c1", 3), ("c1", 2),
                                      ("ref", 4), ("ref", 3), ("c3", 12), ("c3", 11), ("c3", 5),
                                      ("c5s", 20), ("c5s", 15), ("c5s", 8)])

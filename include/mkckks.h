@@ -128,6 +128,17 @@ int mkckks_reencrypt_accumulate_batch(mkckks_ctx *c, const uint64_t *d_ct, const
 int mkckks_modup_batch(mkckks_ctx *c, const uint64_t *d_c1, uint64_t *d_digits, uint32_t n, uint32_t nl);
 int mkckks_moddown_batch(mkckks_ctx *c, const uint64_t *d_in, uint64_t *d_out, uint32_t n, uint32_t nl);
 
+/* ---- randomness for KeyGen / ReKeyGen / Encrypt, generated in HBM ------------
+ * OpenFHE's TernaryUniformGenerator, DiscreteGaussianGenerator (sigma 3.19) and
+ * DiscreteUniformGenerator.  Counter-based Philox4x32-10: element i of `stream_id`
+ * under `seed` is a pure function of (seed, stream_id, i).  Distributional parity only
+ * (OpenFHE's PRNG stream cannot be reproduced).  d_out: int8[count] / int32[count] /
+ * u64[n_polys][nl(+K)][N] (uniform in [0, q_limb), exact by rejection). */
+int mkckks_sample_ternary(mkckks_ctx *c, int8_t *d_out, size_t count, uint64_t seed, uint32_t stream_id);
+int mkckks_sample_gauss(mkckks_ctx *c, int32_t *d_out, size_t count, double sigma, uint64_t seed, uint32_t stream_id);
+int mkckks_sample_uniform(mkckks_ctx *c, uint64_t *d_out, uint32_t n_polys, uint32_t nl, int with_p, uint64_t seed,
+                          uint32_t stream_id);
+
 /* ---- cc->KeyGen()  (client/src/keyGen.cpp:33) -----------------------------
  * randomness is supplied by the caller (host samplers in ppqsflhe_amd/host, or
  * a test's seeded vectors): s ternary int8[N], e int32[N] (COEFFICIENT),

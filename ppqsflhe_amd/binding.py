@@ -68,6 +68,9 @@ SYMBOLS = {
     "mkckks_encrypt_batch": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32]),
     "mkckks_lift_ntt_batch": (_int, [_vp, _vp, _vp, _u32, _u32]),
     "mkckks_decrypt_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32]),
+    "mkckks_sample_ternary": (_int, [_vp, _vp, _sz, C.c_uint64, _u32]),
+    "mkckks_sample_gauss": (_int, [_vp, _vp, _sz, _dbl, C.c_uint64, _u32]),
+    "mkckks_sample_uniform": (_int, [_vp, _vp, _u32, _u32, _int, C.c_uint64, _u32]),
     "mkckks_encode_batch": (_int, [_vp, _vp, _vp, _u32, _u32, _dbl]),
     "mkckks_decode_batch": (_int, [_vp, _vp, _vp, _u32, _u32, _dbl]),
     "mkckks_reduce_mod_batch": (_int, [_vp, _vp, _u32, _u32, _u32]),
@@ -278,6 +281,15 @@ class Context:
 
     def lift_ntt(self, coef, out, n, nl):
         self._check(self._L.mkckks_lift_ntt_batch(self._h, _ptr(coef), _ptr(out), n, nl))
+
+    def sample_ternary(self, out, count, seed, stream_id=0):
+        self._check(self._L.mkckks_sample_ternary(self._h, _ptr(out), count, seed, stream_id))
+
+    def sample_gauss(self, out, count, sigma, seed, stream_id=0):
+        self._check(self._L.mkckks_sample_gauss(self._h, _ptr(out), count, float(sigma), seed, stream_id))
+
+    def sample_uniform(self, out, n_polys, nl, with_p, seed, stream_id=0):
+        self._check(self._L.mkckks_sample_uniform(self._h, _ptr(out), n_polys, nl, int(with_p), seed, stream_id))
 
     def encode(self, vals, pt, n, nl, scale):
         self._check(self._L.mkckks_encode_batch(self._h, _ptr(vals), _ptr(pt), n, nl, float(scale)))

@@ -258,6 +258,25 @@ int mkckks_lift_ntt_batch(mkckks_ctx *c, const double *coef, uint64_t *out, uint
         c->eng->lift_ntt(coef, out, n, nl);
     });
 }
+int mkckks_sample_ternary(mkckks_ctx *c, int8_t *out, size_t count, uint64_t seed, uint32_t stream_id) {
+    return guarded([&] {
+        need(c && out, "null argument");
+        c->eng->sample_ternary(out, count, seed, stream_id);
+    });
+}
+int mkckks_sample_gauss(mkckks_ctx *c, int32_t *out, size_t count, double sigma, uint64_t seed, uint32_t stream_id) {
+    return guarded([&] {
+        need(c && out, "null argument");
+        c->eng->sample_gauss(out, count, sigma, seed, stream_id);
+    });
+}
+int mkckks_sample_uniform(mkckks_ctx *c, uint64_t *out, uint32_t n_polys, uint32_t nl, int with_p, uint64_t seed,
+                          uint32_t stream_id) {
+    return guarded([&] {
+        need(c && out, "null argument");
+        c->eng->sample_uniform(out, n_polys, nl, with_p != 0, seed, stream_id);
+    });
+}
 int mkckks_encode_batch(mkckks_ctx *c, const double *vals, uint64_t *pt, uint32_t n, uint32_t nl, double scale) {
     return guarded([&] {
         need(c && vals && pt, "null argument");

@@ -15,6 +15,7 @@
 #include "engine.hpp"
 #include "ntt_radix.hpp"
 #include "codec_kernels.hpp"
+#include "sampler_kernels.hpp"
 
 #include <cmath>
 #include <cstdlib>
@@ -1053,6 +1054,47 @@ void Engine::decrypt(const u64 *ct, const u64 *sk, u64 *m, uint32_t n_ct, uint32
     k_fma<<<ew_grid(n, nl, n_ct), EW_THREADS, 0, stream_>>>(c1, s, c0, none, nullptr, 0, m, poly, 0, g, d_limb_, nl);
     MK_HIP(hipGetLastError());
     ntt_launch(m, n_ct, nl, nl, true, nullptr, nullptr);
+}
+
+// ---- randomness ------------------------------------------------------------------------------------
+
+void Engine::sample_ternary(int8_t *out, size_t count, uint64_t seed, uint32_t sid) {
+    need_device();
+    if (!count) return;
+    k_sample_ternary<<<(unsigned)((count + 255) / 256), 256, 0, stream_>>>(out, count, seed, sid);
+    MK_HIP(hipGetLastError());
+}
+
+void Engine::sample_gauss(int32_t *out, size_t count, double sigma, uint64_t seed, uint32_t sid) {
+    need_device();
+    if (!count) return;
+    if (!(sigma > 0) || 12.0 * sigma > GAUSS_TABLE - 1) throw std::invalid_argument("sigma out of range");
+    GaussTable t{};
+    t.count = (int)std::ceil(12.0 * sigma) + 1;
+    std::vector<long double> w(t.count);
+    long double total = 0;
+    for (int k = 0; k < t.count; ++k) {
+        w[k] = std::exp(-(long double)k * k / (2.0L * sigma * sigma)) * (k ? 2.0L : 1.0L);
+        total += w[k];
+    }
+    long double acc = 0;
+    for (int k = 0; k < t.count; ++k) {
+        acc += w[k] / total;
+        const long double scaled = acc * 18446744073709551616.0L;
+        t.thr[k] = scaled >= 18446744073709551615.0L ? ~0ull : (u64)scaled;
+    }
+    t.thr[t.count - 1] = ~0ull;
+    k_sample_gauss<<<(unsigned)((count + 255) / 256), 256, 0, stream_>>>(out, count, seed, sid, t);
+    MK_HIP(hipGetLastError());
+}
+
+void Engine::sample_uniform(u64 *out, uint32_t items, uint32_t nl, bool with_p, uint64_t seed, uint32_t sid) {
+    need_device();
+    if (nl > ps_.L || (nl == 0 && !with_p)) throw std::invalid_argument("nl out of range");
+    if (!items) return;
+    const uint32_t slots = nl + (with_p ? ps_.K : 0);
+    k_sample_uniform<<<dim3((ps_.n + 255) / 256, slots, items), 256, 0, stream_>>>(out, ps_.n, nl, ps_.L, d_limb_, seed, sid);
+    MK_HIP(hipGetLastError());
 }
 
 // ---- CKKS encode / decode (fp64 canonical embedding on the device) ---------------------------------

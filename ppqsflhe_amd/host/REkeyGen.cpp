@@ -33,16 +33,15 @@ int main(int argc, char *argv[]) {
             return 1;
         }
         std::cout << "[ReKeyGen] Peer Public Key loaded from " << pk_path << std::endl;
-        Sampler rng;
-        std::vector<int8_t> u((size_t)beta * N);
-        std::vector<int32_t> e0((size_t)beta * N), e1((size_t)beta * N);
-        rng.ternary(u.data(), u.size());
-        rng.gaussian(e0.data(), e0.size());
-        rng.gaussian(e1.data(), e1.size());
+        const uint64_t seed = fresh_seed();
+        int8_t *d_u = s.alloc<int8_t>((size_t)beta * N);
+        int32_t *d_e0 = s.alloc<int32_t>((size_t)beta * N), *d_e1 = s.alloc<int32_t>((size_t)beta * N);
+        Session::check(mkckks_sample_ternary(s.ctx(), d_u, (size_t)beta * N, seed, 0));
+        Session::check(mkckks_sample_gauss(s.ctx(), d_e0, (size_t)beta * N, 3.19, seed, 1));
+        Session::check(mkckks_sample_gauss(s.ctx(), d_e1, (size_t)beta * N, 3.19, seed, 2));
         uint64_t *d_evk = s.alloc<uint64_t>((size_t)beta * 2 * D * N);
-        Session::check(mkckks_rekeygen(s.ctx(), s.to_device(sk_t.data(), N), s.to_device(pk.data(), pk.size()),
-                                       s.to_device(u.data(), u.size()), s.to_device(e0.data(), e0.size()),
-                                       s.to_device(e1.data(), e1.size()), d_evk));
+        Session::check(mkckks_rekeygen(s.ctx(), s.to_device(sk_t.data(), N), s.to_device(pk.data(), pk.size()), d_u, d_e0,
+                                       d_e1, d_evk));
         std::vector<uint64_t> evk((size_t)beta * 2 * D * N);
         s.to_host(evk.data(), d_evk, evk.size());
         std::cout << "[ReKeyGen] Re-encryption key generated successfully" << std::endl;

@@ -76,16 +76,15 @@ int main(int argc, char *argv[]) {
         const size_t slots = s.slots();
         std::vector<double> slot_vals(n_ct * slots, 0.0);  // zero padded to N/2 slots
         for (size_t c = 0; c < n_ct; ++c) std::copy(plains[c].begin(), plains[c].end(), slot_vals.begin() + c * slots);
-        Sampler rng;
-        std::vector<int8_t> v(n_ct * N);
-        std::vector<int32_t> e0(n_ct * N), e1(n_ct * N);
-        rng.ternary(v.data(), v.size());
-        rng.gaussian(e0.data(), e0.size());
-        rng.gaussian(e1.data(), e1.size());
+        const uint64_t seed = fresh_seed();
+        int8_t *d_v = s.alloc<int8_t>(n_ct * N);
+        int32_t *d_e0 = s.alloc<int32_t>(n_ct * N), *d_e1 = s.alloc<int32_t>(n_ct * N);
+        Session::check(mkckks_sample_ternary(s.ctx(), d_v, n_ct * N, seed, 0));
+        Session::check(mkckks_sample_gauss(s.ctx(), d_e0, n_ct * N, 3.19, seed, 1));
+        Session::check(mkckks_sample_gauss(s.ctx(), d_e1, n_ct * N, 3.19, seed, 2));
         uint64_t *d_pt = s.alloc<uint64_t>(n_ct * L * N), *d_ct = s.alloc<uint64_t>(n_ct * 2 * L * N);
         Session::check(mkckks_encode_batch(s.ctx(), s.to_device(slot_vals.data(), slot_vals.size()), d_pt, (uint32_t)n_ct, L, scale));
-        Session::check(mkckks_encrypt_batch(s.ctx(), s.to_device(pk.data(), pk.size()), d_pt, s.to_device(v.data(), v.size()),
-                                            s.to_device(e0.data(), e0.size()), s.to_device(e1.data(), e1.size()), d_ct,
+        Session::check(mkckks_encrypt_batch(s.ctx(), s.to_device(pk.data(), pk.size()), d_pt, d_v, d_e0, d_e1, d_ct,
                                             (uint32_t)n_ct, L));
         std::vector<uint64_t> all(n_ct * 2 * L * N);
         s.to_host(all.data(), d_ct, all.size());

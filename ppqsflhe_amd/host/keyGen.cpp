@@ -1,5 +1,5 @@
 // keyGen -- drop-in for client/src/keyGen.cpp: `keyGen <cc_path> <pubkey_out> <privkey_out>` (keyGen.cpp:14-22).
-// cc->KeyGen() (keyGen.cpp:33) -> mkckks_keygen on the GPU with host-sampled randomness.
+// cc->KeyGen() (keyGen.cpp:33) -> mkckks_sample_* + mkckks_keygen, all on the GPU.
 #include "hostlib.hpp"
 using namespace mkh;
 
@@ -20,16 +20,17 @@ int main(int argc, char *argv[]) {
         Session s(cc);
         std::cout << "[keyGen] CryptoContext loaded from " << cc_path << std::endl;
         const uint32_t N = s.N(), D = s.D();
-        Sampler rng;
-        std::vector<int8_t> sk_t(N);
-        std::vector<int32_t> e(N);
-        std::vector<uint64_t> a((size_t)D * N);
-        rng.ternary(sk_t.data(), N);
-        rng.gaussian(e.data(), N);
-        for (uint32_t i = 0; i < D; ++i) rng.uniform(&a[(size_t)i * N], N, s.moduli()[i]);
+        const uint64_t seed = fresh_seed();
+        int8_t *d_s = s.alloc<int8_t>(N);
+        int32_t *d_e = s.alloc<int32_t>(N);
+        uint64_t *d_a = s.alloc<uint64_t>((size_t)D * N);
+        Session::check(mkckks_sample_ternary(s.ctx(), d_s, N, seed, 0));          // secret: uniform ternary
+        Session::check(mkckks_sample_gauss(s.ctx(), d_e, N, 3.19, seed, 1));       // error: sigma = 3.19
+        Session::check(mkckks_sample_uniform(s.ctx(), d_a, 1, s.L(), 1, seed, 2));  // a: uniform over QP
         uint64_t *d_pk = s.alloc<uint64_t>((size_t)2 * D * N), *d_sk = s.alloc<uint64_t>((size_t)D * N);
-        Session::check(mkckks_keygen(s.ctx(), s.to_device(sk_t.data(), N), s.to_device(a.data(), a.size()),
-                                     s.to_device(e.data(), N), d_pk, d_sk));
+        Session::check(mkckks_keygen(s.ctx(), d_s, d_a, d_e, d_pk, d_sk));
+        std::vector<int8_t> sk_t(N);
+        s.to_host(sk_t.data(), d_s, N);
         std::vector<uint64_t> pk((size_t)2 * D * N), sk((size_t)D * N);
         s.to_host(pk.data(), d_pk, pk.size());
         s.to_host(sk.data(), d_sk, sk.size());

@@ -345,6 +345,41 @@ def test_reencrypt_accumulate(ctxs, name, nl):
         g.reencrypt_accumulate(d_acc, g.to_device(evks[0]), d_acc, B, nl)  # aliasing is refused
 
 
+def test_device_samplers(ctxs):
+    """Philox samplers in HBM: distributional checks (OpenFHE's PRNG stream is not reproducible), determinism per
+    (seed, stream), independence across streams, exact range of the uniform limbs."""
+    g, _ = ctxs("ref")
+    n = 1 << 18
+    d_t = g.empty((n,), dtype=np.int8)
+    g.sample_ternary(d_t, n, 1234, 0)
+    t = d_t.to_host()
+    assert set(np.unique(t)) == {-1, 0, 1}
+    counts = np.bincount(t + 1, minlength=3)
+    assert np.abs(counts - n / 3).max() < 5 * np.sqrt(n * 2 / 9)  # 5 sigma of a multinomial cell
+    g.sample_ternary(d_t, n, 1234, 0)
+    assert np.array_equal(d_t.to_host(), t)  # deterministic
+    g.sample_ternary(d_t, n, 1234, 1)
+    assert not np.array_equal(d_t.to_host(), t)  # another stream
+    assert abs(np.corrcoef(d_t.to_host().astype(float), t.astype(float))[0, 1]) < 0.02
+    d_g = g.empty((n,), dtype=np.int32)
+    g.sample_gauss(d_g, n, 3.19, 99, 0)
+    e = d_g.to_host().astype(np.float64)
+    assert abs(e.mean()) < 5 * 3.19 / np.sqrt(n)
+    assert abs(e.var() - 3.19 ** 2) < 0.15  # discrete Gaussian: variance = sigma^2 up to ~1e-8
+    assert np.abs(e).max() <= 39
+    # P(0) of D_{Z,sigma}
+    S = sum(np.exp(-k * k / (2 * 3.19 ** 2)) for k in range(-60, 61))
+    assert abs((e == 0).mean() - 1 / S) < 5 * np.sqrt((1 / S) / n)
+    d_u = g.empty((2, g.D, g.N))
+    g.sample_uniform(d_u, 2, g.L, True, 7, 3)
+    u = d_u.to_host()
+    for i in range(g.D):
+        q = int(g.moduli[i])
+        assert u[:, i].max() < q
+        assert abs(u[:, i].astype(np.float64).mean() / q - 0.5) < 5 * np.sqrt(1 / 12 / (2 * g.N))
+    assert not np.array_equal(u[0], u[1])
+
+
 def test_empty_batches_are_noops(ctxs):
     g, _ = ctxs("tiny")
     d = g.empty((1, 2, g.L, g.N))

@@ -407,6 +407,8 @@ __global__ void k_fma(Opnd x, Opnd y, Opnd z, Opnd w, const u64 *wc, int negate_
 // Engine
 // =====================================================================================
 
+static int fast_log_h(uint32_t log_r, uint32_t other_extent);
+
 static dim3 ew_grid(uint32_t n, uint32_t slots, uint32_t items) {
     return dim3((n / 2 + EW_THREADS - 1) / EW_THREADS, slots, items);
 }
@@ -422,6 +424,25 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
         throw NoDevice("no HIP device " + std::to_string(device_) + " (found " + std::to_string(count) + ")");
     MK_HIP(hipSetDevice(device_));
     const uint32_t D = ps_.D, n = ps_.n;
+    // N = R1 x R2 with R1 <= R2; even splits of even log N land on the radix-H kernels (16/64/256)
+    tabs_.log_n = ps_.log_n;
+    tabs_.log_r1 = (ps_.log_n % 2 == 0) ? ((ps_.log_n / 2) & ~1u) : ps_.log_n / 2;
+    tabs_.log_r2 = ps_.log_n - tabs_.log_r1;
+    if (const char *e = std::getenv("MKCKKS_GENERIC_NTT"))
+        if (std::atoi(e) == 1) { tabs_.log_r1 = ps_.log_n / 2; tabs_.log_r2 = ps_.log_n - tabs_.log_r1; }
+    // fp64 limbs: only when BOTH passes run on the radix kernels (the generic LDS-stage kernels are integer-only)
+    // and the modulus is below 1.25 * 2^50 (bounds in ntt_radix.hpp).  MKCKKS_NO_FP64=1 keeps everything integer.
+    const bool radix_both = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) && fast_log_h(tabs_.log_r2, 1u << tabs_.log_r1);
+    const char *nofp = std::getenv("MKCKKS_NO_FP64");
+    const bool fp_ok = radix_both && !(nofp && std::atoi(nofp) == 1);
+    tabs_.has_fp = 0;
+    fp_of_.assign(D, 0);
+    for (uint32_t i = 0; i < D; ++i) {
+        ps_.limb[i].fp = (fp_ok && ps_.moduli[i] < (5ull << 48)) ? 1u : 0u;
+        fp_of_[i] = (uint8_t)ps_.limb[i].fp;
+        tabs_.has_fp |= ps_.limb[i].fp;
+    }
+    tabs_.h_fp_of = fp_of_.data();
     MK_HIP(hipMalloc(&d_limb_, D * sizeof(LimbConst)));
     MK_HIP(hipMemcpy(d_limb_, ps_.limb.data(), D * sizeof(LimbConst), hipMemcpyHostToDevice));
     const size_t tbytes = (size_t)D * n * sizeof(u64);
@@ -430,11 +451,21 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
     MK_HIP(hipMalloc(&d_itw_, tbytes));
     MK_HIP(hipMalloc(&d_itw_sh_, tbytes));
     std::vector<u64> w, wsh;
+    auto as_fp = [&](uint32_t i) {  // (w, Shoup companion) -> (double w, double w/q) bit patterns
+        const long double q = (long double)ps_.moduli[i];
+        for (uint32_t k = 0; k < n; ++k) {
+            const double wd = (double)w[k], wq = (double)((long double)w[k] / q);
+            std::memcpy(&w[k], &wd, 8);
+            std::memcpy(&wsh[k], &wq, 8);
+        }
+    };
     for (uint32_t i = 0; i < D; ++i) {
         ps_.twiddles(i, false, w, wsh);
+        if (ps_.limb[i].fp) as_fp(i);
         MK_HIP(hipMemcpy(d_tw_ + (size_t)i * n, w.data(), n * sizeof(u64), hipMemcpyHostToDevice));
         MK_HIP(hipMemcpy(d_tw_sh_ + (size_t)i * n, wsh.data(), n * sizeof(u64), hipMemcpyHostToDevice));
         ps_.twiddles(i, true, w, wsh);
+        if (ps_.limb[i].fp) as_fp(i);
         MK_HIP(hipMemcpy(d_itw_ + (size_t)i * n, w.data(), n * sizeof(u64), hipMemcpyHostToDevice));
         MK_HIP(hipMemcpy(d_itw_sh_ + (size_t)i * n, wsh.data(), n * sizeof(u64), hipMemcpyHostToDevice));
     }
@@ -456,12 +487,6 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
     }
     tabs_.limb = d_limb_;
     tabs_.tw = d_tw_; tabs_.tw_sh = d_tw_sh_; tabs_.itw = d_itw_; tabs_.itw_sh = d_itw_sh_;
-    tabs_.log_n = ps_.log_n;
-    // N = R1 x R2 with R1 <= R2; even splits of even log N land on the radix-H kernels (16/64/256)
-    tabs_.log_r1 = (ps_.log_n % 2 == 0) ? ((ps_.log_n / 2) & ~1u) : ps_.log_n / 2;
-    tabs_.log_r2 = ps_.log_n - tabs_.log_r1;
-    if (const char *e = std::getenv("MKCKKS_GENERIC_NTT"))
-        if (std::atoi(e) == 1) { tabs_.log_r1 = ps_.log_n / 2; tabs_.log_r2 = ps_.log_n - tabs_.log_r1; }
     tabs_.L = ps_.L;
 }
 
@@ -473,6 +498,10 @@ Engine::~Engine() {
                     (void *)d_rot_, (void *)d_ksi_})
         if (p) (void)hipFree(p);
     for (void *p : owned_) (void)hipFree(p);
+}
+
+void Engine::need_device() const {
+    if (device_ < 0) throw NoDevice("host-only context: no device operations");
 }
 
 void Engine::sync() {
@@ -604,36 +633,74 @@ static int fast_log_h(uint32_t log_r, uint32_t other_extent) {
 }
 
 // pack != 0 (inverse radix kernels only): results leave as packed 30-bit halves for k_conv_col
+// slots of `io` whose limb runs on the fp64 (want_fp) or the integer instance; fp_of: per-limb-id class (host copy)
+static unsigned long long class_mask(const NttIo &io, const unsigned char *fp_of, uint32_t L, bool want_fp) {
+    unsigned long long m = 0;
+    for (uint32_t b = 0; b < io.nslots; ++b) {
+        const uint32_t v = io.vslot0 + b, id = v < io.nl ? v : L + (v - io.nl);
+        if ((fp_of[id] != 0) == want_fp) m |= 1ull << b;
+    }
+    return m;
+}
+
 template <bool INV>
-static void launch_col(const NttIo &io, const NttTables &T, uint32_t n_polys, const u64 *scale, const u64 *scale_sh,
+static void launch_col(const NttIo &io0, const NttTables &T, uint32_t n_polys, const u64 *scale, const u64 *scale_sh,
                        hipStream_t s, int pack = 0) {
     const uint32_t r1 = 1u << T.log_r1, r2 = 1u << T.log_r2;
-    const uint32_t items = n_polys * io.nslots;
+    NttIo io = io0, iof = io0;
+    io.slot_mask = class_mask(io0, T.h_fp_of, T.L, false);
+    iof.slot_mask = class_mask(io0, T.h_fp_of, T.L, true);
+    io.nsel = (uint32_t)__builtin_popcountll(io.slot_mask);
+    iof.nsel = (uint32_t)__builtin_popcountll(iof.slot_mask);
+    const uint32_t items = n_polys * io.nsel, itemsf = n_polys * iof.nsel;
     switch (fast_log_h(T.log_r1, r2)) {
-        case 4: k_ntt_col_r<4, INV><<<dim3(r2 / 16, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); break;
-        case 3: k_ntt_col_r<3, INV><<<dim3(r2 / 32, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); break;
-        case 2: k_ntt_col_r<2, INV><<<dim3(r2 / 64, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); break;
+        case 4:
+            if (items) k_ntt_col_r<4, INV, false><<<dim3(r2 / 16, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack);
+            if (itemsf) k_ntt_col_r<4, INV, true><<<dim3(r2 / 16, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack);
+            break;
+        case 3:
+            if (items) k_ntt_col_r<3, INV, false><<<dim3(r2 / 32, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack);
+            if (itemsf) k_ntt_col_r<3, INV, true><<<dim3(r2 / 32, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack);
+            break;
+        case 2:
+            if (items) k_ntt_col_r<2, INV, false><<<dim3(r2 / 64, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack);
+            if (itemsf) k_ntt_col_r<2, INV, true><<<dim3(r2 / 64, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack);
+            break;
         default:
             if (pack) throw std::logic_error("packed output needs the radix column kernel");
-            k_ntt_col<INV><<<dim3(r2 / NTT_COLS, items), NTT_THREADS, (size_t)r1 * NTT_COLS * sizeof(u64), s>>>(
-                io, T, scale, scale_sh);
+            k_ntt_col<INV><<<dim3(r2 / NTT_COLS, n_polys * io0.nslots), NTT_THREADS, (size_t)r1 * NTT_COLS * sizeof(u64), s>>>(
+                io0, T, scale, scale_sh);
     }
 }
 
 static bool row_tail_supported(const NttTables &T) { return fast_log_h(T.log_r2, 1u << T.log_r1) != 0; }
 
 template <bool INV>
-static void launch_row(const NttIo &io, const NttTables &T, uint32_t n_polys, const TailArgs &tail, hipStream_t s) {
+static void launch_row(const NttIo &io0, const NttTables &T, uint32_t n_polys, const TailArgs &tail, hipStream_t s) {
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
-    const uint32_t items = n_polys * io.nslots;
+    NttIo io = io0, iof = io0;
+    io.slot_mask = class_mask(io0, T.h_fp_of, T.L, false);
+    iof.slot_mask = class_mask(io0, T.h_fp_of, T.L, true);
+    io.nsel = (uint32_t)__builtin_popcountll(io.slot_mask);
+    iof.nsel = (uint32_t)__builtin_popcountll(iof.slot_mask);
+    const uint32_t items = n_polys * io.nsel, itemsf = n_polys * iof.nsel;
     switch (fast_log_h(T.log_r2, r1)) {
-        case 4: k_ntt_row_r<4, INV><<<dim3((r1 / 16) * items), NTT_THREADS, 0, s>>>(io, T, tail); break;
-        case 3: k_ntt_row_r<3, INV><<<dim3((r1 / 32) * items), NTT_THREADS, 0, s>>>(io, T, tail); break;
-        case 2: k_ntt_row_r<2, INV><<<dim3((r1 / 64) * items), NTT_THREADS, 0, s>>>(io, T, tail); break;
+        case 4:
+            if (items) k_ntt_row_r<4, INV, false><<<dim3((r1 / 16) * items), NTT_THREADS, 0, s>>>(io, T, tail);
+            if (itemsf) k_ntt_row_r<4, INV, true><<<dim3((r1 / 16) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail);
+            break;
+        case 3:
+            if (items) k_ntt_row_r<3, INV, false><<<dim3((r1 / 32) * items), NTT_THREADS, 0, s>>>(io, T, tail);
+            if (itemsf) k_ntt_row_r<3, INV, true><<<dim3((r1 / 32) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail);
+            break;
+        case 2:
+            if (items) k_ntt_row_r<2, INV, false><<<dim3((r1 / 64) * items), NTT_THREADS, 0, s>>>(io, T, tail);
+            if (itemsf) k_ntt_row_r<2, INV, true><<<dim3((r1 / 64) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail);
+            break;
         default: {
             if (tail.enabled) throw std::logic_error("fused tail needs the radix row kernel");
             const uint32_t tile = n < (uint32_t)NTT_TILE ? n : (uint32_t)NTT_TILE;
-            k_ntt_row<INV><<<dim3(n / tile, items), NTT_THREADS, (size_t)tile * sizeof(u64), s>>>(io, T);
+            k_ntt_row<INV><<<dim3(n / tile, n_polys * io0.nslots), NTT_THREADS, (size_t)tile * sizeof(u64), s>>>(io0, T);
         }
     }
 }
@@ -660,18 +727,48 @@ static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inve
 // base conversion fused into the forward column pass of every converted limb (k_conv_col); false when the
 // column pass of this ring size has no radix kernel (the caller then runs k_baseconv + a plain column pass)
 template <int LOG_H>
-static void launch_conv_col_h(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s) {
+static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, hipStream_t s) {
     const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
-    const dim3 grid(io.items * tiles * cv.n_out);
+    ConvIo io = io0, iof = io0;
+    io.target_mask = iof.target_mask = 0;
+    for (uint32_t j = 0; j < cv.n_out; ++j)
+        (T.h_fp_of[cv.dst_id[j]] ? iof.target_mask : io.target_mask) |= 1ull << j;
+    io.nsel = (uint32_t)__builtin_popcountll(io.target_mask);
+    iof.nsel = (uint32_t)__builtin_popcountll(iof.target_mask);
+    const dim3 grid(io.items * tiles * io.nsel), gridf(io.items * tiles * iof.nsel);
     switch (cv.n_in) {
-        case 1: k_conv_col<LOG_H, 1, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 2: k_conv_col<LOG_H, 2, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 3: k_conv_col<LOG_H, 3, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 4: k_conv_col<LOG_H, 4, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 5: k_conv_col<LOG_H, 5, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 6: k_conv_col<LOG_H, 6, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 7: k_conv_col<LOG_H, 7, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 8: k_conv_col<LOG_H, 8, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 1:
+            if (io.nsel) k_conv_col<LOG_H, 1, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
+            if (iof.nsel) k_conv_col<LOG_H, 1, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            break;
+        case 2:
+            if (io.nsel) k_conv_col<LOG_H, 2, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
+            if (iof.nsel) k_conv_col<LOG_H, 2, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            break;
+        case 3:
+            if (io.nsel) k_conv_col<LOG_H, 3, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
+            if (iof.nsel) k_conv_col<LOG_H, 3, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            break;
+        case 4:
+            if (io.nsel) k_conv_col<LOG_H, 4, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
+            if (iof.nsel) k_conv_col<LOG_H, 4, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            break;
+        case 5:
+            if (io.nsel) k_conv_col<LOG_H, 5, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
+            if (iof.nsel) k_conv_col<LOG_H, 5, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            break;
+        case 6:
+            if (io.nsel) k_conv_col<LOG_H, 6, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
+            if (iof.nsel) k_conv_col<LOG_H, 6, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            break;
+        case 7:
+            if (io.nsel) k_conv_col<LOG_H, 7, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
+            if (iof.nsel) k_conv_col<LOG_H, 7, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            break;
+        case 8:
+            if (io.nsel) k_conv_col<LOG_H, 8, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
+            if (iof.nsel) k_conv_col<LOG_H, 8, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            break;
         default: throw std::invalid_argument("base conversion fan-in unsupported");
     }
 }
@@ -792,8 +889,15 @@ const u64 *Engine::folded_scale(uint32_t nl) {
     std::vector<u64> v(2 * D, 0);
     auto put = [&](uint32_t id, u64 hatinv) {
         const u64 q = ps_.moduli[id];
-        v[id] = h_mulmod(ps_.limb[id].ninv, hatinv, q);
-        v[D + id] = h_shoup(v[id], q);
+        const u64 c = h_mulmod(ps_.limb[id].ninv, hatinv, q);
+        if (ps_.limb[id].fp) {  // the inverse column pass of an fp limb scales with (double c, double c/q)
+            const double cd = (double)c, cq = (double)((long double)c / (long double)q);
+            std::memcpy(&v[id], &cd, 8);
+            std::memcpy(&v[D + id], &cq, 8);
+        } else {
+            v[id] = c;
+            v[D + id] = h_shoup(c, q);
+        }
     };
     for (uint32_t part = 0; part < ps_.num_parts(nl); ++part) {
         BaseConvTable t = ps_.modup_table(nl, part);
@@ -829,7 +933,7 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
     const size_t dstride = (size_t)nparts * ext * n;
     for (uint32_t part = 0; part < nparts && fused; ++part) {
         // S2+S3a: base conversion fused into the column pass of each complement limb
-        ConvIo io{coef, dig + (size_t)part * ext * n, (size_t)nl * n, dstride, cnt};
+        ConvIo io{coef, dig + (size_t)part * ext * n, (size_t)nl * n, dstride, cnt, 0, 0};
         launch_conv_col(io, tabs_, modup_conv(nl, part), stream_);
     }
     if (fused) {
@@ -865,7 +969,7 @@ void Engine::moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t o
     NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
     ntt_passes(s5, tabs_, cnt, true, fold, fold + D, stream_, fused ? 1 : 0);
     const DevConv &cv = moddown_conv(nl);
-    ConvIo io{pc, conv, (size_t)K * n, (size_t)nl * n, cnt};
+    ConvIo io{pc, conv, (size_t)K * n, (size_t)nl * n, cnt, 0, 0};
     EwGeom g{n, nl, ps_.L};
     if (fused) {
         launch_conv_col(io, tabs_, cv, stream_);

@@ -94,9 +94,7 @@ public:
     void host_twiddles(uint32_t limb, bool inverse, std::vector<u64> &out) const;
 
 private:
-    void need_device() const {
-        if (device_ < 0) throw NoDevice("host-only context: no device operations");
-    }
+    void need_device() const;
     void check_nl(uint32_t nl) const;
     u64 *workspace(size_t words);  // grow-only scratch arena (stream-ordered reuse)
     const DevConv &modup_conv(uint32_t nl, uint32_t part);
@@ -117,6 +115,7 @@ private:
     NttTables tabs_{};
     LimbConst *d_limb_ = nullptr;
     u64 *d_tw_ = nullptr, *d_tw_sh_ = nullptr, *d_itw_ = nullptr, *d_itw_sh_ = nullptr;
+    std::vector<uint8_t> fp_of_;  // per limb id: 1 = fp64 kernel instance
     uint32_t *d_rot_ = nullptr;
     void *d_ksi_ = nullptr;
     u64 *ws_ = nullptr;

@@ -36,6 +36,14 @@ struct LimbConst {
     u64 ninv_sh;  // Shoup companion of ninv
     uint32_t k;   // bit length of q
     uint32_t sh;  // k - 2: window shift for Barrett
+    // fp64 path (limbs with q < 1.25 * 2^50 when the engine enables it): transforms of such a limb run on
+    // v_fma_f64 (53-bit exact products) instead of the 32-bit integer multiplier
+    double qd;        // (double) q
+    double qinv;      // 1 / q
+    double ninv_d;    // (double) N^-1 mod q
+    double ninv_qd;   // ninv_d / q
+    uint32_t fp;      // 1: this limb's NTT tables hold doubles (w, w/q) and its inter-pass data are doubles
+    uint32_t pad_;
 };
 
 MK_HD u64 mulhi64(u64 a, u64 b) {
@@ -112,6 +120,30 @@ MK_HD u64 reduce_wide(u64 hi, u64 lo, const LimbConst &L) {
 
 // reduce one 64-bit word mod q (q may be much smaller than 2^64)
 MK_HD u64 reduce_word(u64 x, const LimbConst &L) { return barrett_reduce128(0, x, L); }
+
+// ---- exact modular arithmetic on fp64 FMAs (q < 1.25 * 2^50) --------------------------------------
+// Residues are integers held in doubles.  y*w = h + l exactly (h = RN(y*w), l = fma(y,w,-h)); b = rint(y * (w/q))
+// is the quotient within 1.5 for |y| <= 2^52; h - b*q is an integer below 2^53, so fma(-b,q,h) is exact and
+// v = (h - b*q) + l = y*w - b*q exactly, |v| <= q * (0.5 + 1.0001 |y| / 2^52).   (tools/ubench_fpmod.hip: 0
+// mismatches in 6.5e9 trials against integer arithmetic, incl. q just below 2^51.)
+#if defined(__HIPCC__)
+MK_D double fp_mulmod(double y, double w, double wq, double q) {
+    const double h = __dmul_rn(y, w);
+    const double l = __fma_rn(y, w, -h);
+    const double b = rint(__dmul_rn(y, wq));
+    const double c = __fma_rn(-b, q, h);
+    return __dadd_rn(c, l);
+}
+// x - q*rint(x/q): |result| <= 0.51 q for |x| < 2^53 (exact: the fma's true value is an integer below 2^53)
+MK_D double fp_reduce(double x, double q, double qinv) { return __fma_rn(-rint(__dmul_rn(x, qinv)), q, x); }
+MK_D u64 fp_to_canonical(double x, double q, double qinv) {
+    double r = fp_reduce(x, q, qinv);
+    r = r < 0.0 ? r + q : r;
+    return (u64)r;
+}
+MK_D u64 dbits(double d) { return (u64)__double_as_longlong(d); }
+MK_D double bitsd(u64 b) { return __longlong_as_double((long long)b); }
+#endif
 
 // ---- column accumulation for sums of products of 60-bit numbers ----------------------------------
 // a = a1*2^30 + a0, b = b1*2^30 + b0 (all four halves < 2^30):  sum_i a_i*b_i = C0 + C1*2^30 + C2*2^60 with

@@ -34,6 +34,8 @@ struct NttTables {
     const u64 *itw, *itw_sh;
     uint32_t log_n, log_r1, log_r2;
     uint32_t L;  // #Q limbs at full level (P limbs start at id L)
+    uint32_t has_fp;  // some limbs run on the fp64 kernel instances (host launches both instances then)
+    const unsigned char *h_fp_of;  // HOST pointer (never read on the device): per limb id, 1 = fp64 instance
 };
 
 struct NttIo {
@@ -47,7 +49,16 @@ struct NttIo {
     // digit buffers [item][part][ext][N]: polynomial p belongs to digit p % skip_nparts, whose own limbs
     // [part*skip_alpha, min(nl, (part+1)*skip_alpha)) are not transformed (0 = transform everything)
     uint32_t skip_nparts = 0, skip_alpha = 0;
+    // the radix kernels come in an integer and an fp64 instance; each is launched over the slots of its class
+    // only: bit b of slot_mask = slot (in_slot0 + b) belongs to this launch, nsel = popcount(slot_mask)
+    unsigned long long slot_mask = ~0ull;
+    uint32_t nsel = 0;
 };
+
+MK_D uint32_t nth_set_bit(unsigned long long mask, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) mask &= mask - 1;
+    return (uint32_t)__builtin_ctzll(mask);
+}
 
 MK_D bool ntt_slot_skipped(const NttIo &io, uint32_t poly, uint32_t vslot) {
     if (!io.skip_nparts) return false;

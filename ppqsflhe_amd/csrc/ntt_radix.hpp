@@ -67,6 +67,64 @@ MK_D void radix_inverse(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], 
     }
 }
 
+// ---- fp64 rounds (limbs with LimbConst::fp): x[], w[], wq[] hold DOUBLE bit patterns -----------------
+// forward: u = reduce(x) (|u| <= 0.51q), v = y*w mod q (|v| <= q(0.5 + 1.0001|y|/2^52)); with q < 1.25*2^50 the
+// fixed point of the bound is |value| <= 1.47q.  inverse: s = x + y is reduced, d = x - y goes straight into the
+// product (|d| <= 2.66q < 2^52.1, product output <= 1.33q).  Everything stays an exact integer below 2^53.
+MK_D void ct_butterfly_fp(u64 &xb, u64 &yb, u64 wb, u64 wqb, double q, double qinv) {
+    const double v = fp_mulmod(bitsd(yb), bitsd(wb), bitsd(wqb), q);
+    const double u = fp_reduce(bitsd(xb), q, qinv);
+    xb = dbits(u + v);
+    yb = dbits(u - v);
+}
+MK_D void gs_butterfly_fp(u64 &xb, u64 &yb, u64 wb, u64 wqb, double q, double qinv) {
+    const double x = bitsd(xb), y = bitsd(yb);
+    xb = dbits(fp_reduce(x + y, q, qinv));
+    yb = dbits(fp_mulmod(x - y, bitsd(wb), bitsd(wqb), q));
+}
+template <int LOG_H>
+MK_D void radix_forward_fp(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], const u64 (&wq)[(1 << LOG_H) - 1],
+                           double q, double qinv) {
+    constexpr int H = 1 << LOG_H;
+#pragma unroll
+    for (int s = 0; s < LOG_H; ++s) {
+        const int dist = H >> (s + 1);
+#pragma unroll
+        for (int p = 0; p < H / 2; ++p) {
+            const int g = p / dist, k0 = g * 2 * dist + (p % dist);
+            ct_butterfly_fp(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wq[(1 << s) - 1 + g], q, qinv);
+        }
+    }
+}
+template <int LOG_H>
+MK_D void radix_inverse_fp(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], const u64 (&wq)[(1 << LOG_H) - 1],
+                           double q, double qinv) {
+    constexpr int H = 1 << LOG_H;
+#pragma unroll
+    for (int s = LOG_H - 1; s >= 0; --s) {
+        const int dist = H >> (s + 1);
+#pragma unroll
+        for (int p = 0; p < H / 2; ++p) {
+            const int g = p / dist, k0 = g * 2 * dist + (p % dist);
+            gs_butterfly_fp(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wq[(1 << s) - 1 + g], q, qinv);
+        }
+    }
+}
+// dispatch on the arithmetic of the kernel instance (FP is a template parameter of every radix kernel: the two
+// arithmetics get their own register allocation; a launch of one instance skips the limbs of the other class)
+template <int LOG_H, bool FP>
+MK_D void radix_forward_any(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], const u64 (&wp)[(1 << LOG_H) - 1],
+                            const LimbConst &lc) {
+    if (FP) radix_forward_fp<LOG_H>(x, w, wp, lc.qd, lc.qinv);
+    else radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
+}
+template <int LOG_H, bool FP>
+MK_D void radix_inverse_any(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], const u64 (&wp)[(1 << LOG_H) - 1],
+                            const LimbConst &lc) {
+    if (FP) radix_inverse_fp<LOG_H>(x, w, wp, lc.qd, lc.qinv);
+    else radix_inverse<LOG_H>(x, w, wp, lc.q, lc.q2);
+}
+
 // ---- LDS layouts -------------------------------------------------------------------
 // column tile: R rows x S columns (S = 256/H), stored as H blocks of H rows; blocks are padded by
 // 16 words when S == 16 so that two neighbouring blocks land in different halves of a bank row.
@@ -118,37 +176,38 @@ struct RowTwA {
 
 // Forward column pass, everything after the H input words of this thread (rows j + H k, column c) are
 // in x[]: round A, LDS exchange, round B, store rows H j + k (lazy [0,8q): the row pass finishes).
-template <int LOG_H>
+template <int LOG_H, bool FP>
 MK_D void col_forward_finish(u64 (&x)[1 << LOG_H], u64 *lds, const u64 *tw, const u64 *tw_sh, const LimbConst &lc,
                              int j, int c, u64 *dst_col, uint32_t r2) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H;
     u64 w[H - 1], wp[H - 1];
     load_round_twiddles<LOG_H>(tw, tw_sh, 1u, w, wp);  // same for every column: scalar loads
-    radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
+    radix_forward_any<LOG_H, FP>(x, w, wp, lc);
 #pragma unroll
     for (int k = 0; k < H; ++k) lds[TL::at(k, j, c)] = x[k];  // row j + H k
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < H; ++k) x[k] = lds[TL::at(j, k, c)];  // row H j + k
     load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w, wp);
-    radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
+    radix_forward_any<LOG_H, FP>(x, w, wp, lc);
 #pragma unroll
-    for (int k = 0; k < H; ++k) dst_col[(size_t)(H * j + k) * r2] = x[k];
+    for (int k = 0; k < H; ++k) dst_col[(size_t)(H * j + k) * r2] = x[k];  // lazy u64, or doubles on an fp limb
 }
 
 // Column pass over R1 = H*H rows: one workgroup = S = 256/H adjacent columns.  Global accesses are
 // S x 8-B row segments (128 B at H = 16); one LDS exchange between the two rounds.
-template <int LOG_H, bool INV>
+template <int LOG_H, bool INV, bool FP>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T, const u64 *scale,
                                                            const u64 *scale_sh, int pack) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
     __shared__ u64 lds[TL::WORDS];
-    const uint32_t poly = blockIdx.y / io.nslots, sl = blockIdx.y % io.nslots;
+    const uint32_t poly = blockIdx.y / io.nsel, sl = nth_set_bit(io.slot_mask, blockIdx.y % io.nsel);
     if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;  // block-uniform
     const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
     const LimbConst lc = T.limb[id];
+    if ((lc.fp != 0) != FP) return;  // never: the host selects the slots of this instance's class
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2;
     const int c = threadIdx.x % S, j = threadIdx.x / S;
     const u64 *src = io.in + (size_t)poly * io.in_stride + (size_t)(io.in_slot0 + sl) * n + blockIdx.x * S + c;
@@ -159,24 +218,31 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
     if (!INV) {
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = src[(size_t)(j + H * k) * r2];
-        col_forward_finish<LOG_H>(x, lds, tw, tw_sh, lc, j, c, dst, r2);
+        if (FP) {  // canonical residues -> doubles (exact, q < 2^51)
+#pragma unroll
+            for (int k = 0; k < H; ++k) x[k] = dbits((double)x[k]);
+        }
+        col_forward_finish<LOG_H, FP>(x, lds, tw, tw_sh, lc, j, c, dst, r2);
     } else {
         u64 w[H - 1], wp[H - 1];
 #pragma unroll
-        for (int k = 0; k < H; ++k) x[k] = src[(size_t)(H * j + k) * r2];
+        for (int k = 0; k < H; ++k) x[k] = src[(size_t)(H * j + k) * r2];  // from the row pass: doubles on an fp limb
         load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w, wp);
-        radix_inverse<LOG_H>(x, w, wp, lc.q, lc.q2);
+        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(j, k, c)] = x[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(k, j, c)];
         load_round_twiddles<LOG_H>(tw, tw_sh, 1u, w, wp);
-        radix_inverse<LOG_H>(x, w, wp, lc.q, lc.q2);
-        const u64 sc = scale ? scale[id] : lc.ninv, sc_sh = scale ? scale_sh[id] : lc.ninv_sh;
+        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
+        // scale by N^-1 (x folded constant): table entries are (u64, Shoup) or, on an fp limb, (double, double/q)
+        const u64 sc = scale ? scale[id] : (FP ? dbits(lc.ninv_d) : lc.ninv);
+        const u64 sc_sh = scale ? scale_sh[id] : (FP ? dbits(lc.ninv_qd) : lc.ninv_sh);
 #pragma unroll
         for (int k = 0; k < H; ++k) {
-            const u64 v = shoup_mul(x[k], sc, sc_sh, lc.q);
+            const u64 v = FP ? fp_to_canonical(fp_mulmod(bitsd(x[k]), bitsd(sc), bitsd(sc_sh), lc.qd), lc.qd, lc.qinv)
+                                : shoup_mul(x[k], sc, sc_sh, lc.q);
             dst[(size_t)(j + H * k) * r2] = pack ? pack30(v) : v;  // packed halves feed k_conv_col directly
         }
     }
@@ -193,8 +259,10 @@ struct ConvIo {
     u64 *out;           // [items][out_slots][N]
     size_t in_stride, out_stride;
     uint32_t items;
+    unsigned long long target_mask;  // targets (indices into cv.dst_*) of this instance's arithmetic class
+    uint32_t nsel;                   // popcount(target_mask)
 };
-template <int LOG_H, int N_IN, typename CONV>
+template <int LOG_H, int N_IN, bool FP, typename CONV>
 __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T, CONV cv) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
@@ -204,15 +272,17 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
     uint32_t grp, jt;
     if (groups % 8 == 0) {  // XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch)
         const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / cv.n_out) * 8 + xcd;
-        jt = qidx % cv.n_out;
+        grp = (qidx / io.nsel) * 8 + xcd;
+        jt = qidx % io.nsel;
     } else {
-        grp = blockIdx.x / cv.n_out;
-        jt = blockIdx.x % cv.n_out;
+        grp = blockIdx.x / io.nsel;
+        jt = blockIdx.x % io.nsel;
     }
+    jt = nth_set_bit(io.target_mask, jt);
     const uint32_t item = grp / tiles, tile = grp % tiles;
     const uint32_t id = cv.dst_id[jt];
     const LimbConst lc = T.limb[id];
+    if ((lc.fp != 0) != FP) return;  // block-uniform
     const int c = threadIdx.x % S, j = threadIdx.x / S;
     const u64 *src = io.in + (size_t)item * io.in_stride + tile * S + c;
     u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jt] * n + tile * S + c;
@@ -245,7 +315,11 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
             x[k] = reduce_wide(hi, lo, lc);
         }
     }
-    col_forward_finish<LOG_H>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
+    if (FP) {  // < 4q < 2^53: exact in a double; bring into the fp rounds' range
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = dbits(fp_reduce((double)x[k], lc.qd, lc.qinv));
+    }
+    col_forward_finish<LOG_H, FP>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
 }
 
 // ApproxModDown tail folded into the copy-out of the forward row pass:
@@ -262,7 +336,7 @@ struct TailArgs {
 
 // Row pass over rows of R2 = H*H contiguous words: one workgroup = S consecutive rows (S*R2 contiguous
 // words).  The side that needs per-thread contiguous runs goes through LDS with coalesced 16-B accesses.
-template <int LOG_H, bool INV>
+template <int LOG_H, bool INV, bool FP>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T, TailArgs tail) {
     using TL = RowTile<LOG_H>;
     using TA = RowTwA<LOG_H>;
@@ -273,7 +347,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
     // 2*S*R-word twiddle tile: they are made consecutive inside ONE XCD's queue (blocks b, b+8, ... share an
     // XCD under round-robin dispatch) so the tile is fetched over the fabric once and then hits in that L2.
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
-    const uint32_t tiles = r1 / S, groups = tiles * io.nslots, n_polys = gridDim.x / groups;
+    const uint32_t tiles = r1 / S, groups = tiles * io.nsel, n_polys = gridDim.x / groups;
     uint32_t grp, poly;
     if (groups % 8 == 0) {
         const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
@@ -283,10 +357,11 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         grp = blockIdx.x / n_polys;
         poly = blockIdx.x % n_polys;
     }
-    const uint32_t sl = grp / tiles;
+    const uint32_t sl = nth_set_bit(io.slot_mask, grp / tiles);
     if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;  // block-uniform
     const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
     const LimbConst lc = T.limb[id];
+    if ((lc.fp != 0) != FP) return;  // block-uniform
     const uint32_t row0 = (grp % tiles) * S;
     const int g = threadIdx.x / H, j = threadIdx.x % H;
     const u64 *src = io.in + (size_t)poly * io.in_stride + (size_t)(io.in_slot0 + sl) * n + (size_t)row0 * R;
@@ -301,16 +376,17 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         TA::stage(twa, twa_sh, tw, tw_sh, r1 + row0);
         __syncthreads();
         TA::fetch(twa, twa_sh, g, w, wp);
-        radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
+        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
         load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);
-        radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
+        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
 #pragma unroll
-        for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = canon8(x[k], lc.q, lc.q2);  // own words only
+        for (int k = 0; k < H; ++k)  // canonical u64, own words only
+            lds[TL::at(g, H * j + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
         __syncthreads();
         if (!tail.enabled) {
             for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
@@ -356,17 +432,21 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
+        if (FP) {  // canonical input -> doubles
+#pragma unroll
+            for (int k = 0; k < H; ++k) x[k] = dbits((double)x[k]);
+        }
         load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);
-        radix_inverse<LOG_H>(x, w, wp, lc.q, lc.q2);
+        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = x[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, j + H * k)];
         TA::fetch(twa, twa_sh, g, w, wp);
-        radix_inverse<LOG_H>(x, w, wp, lc.q, lc.q2);
+        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
 #pragma unroll
-        for (int k = 0; k < H; ++k) dst[(size_t)g * R + j + H * k] = x[k];  // lazy [0,2q): the column pass scales
+        for (int k = 0; k < H; ++k) dst[(size_t)g * R + j + H * k] = x[k];  // lazy [0,2q) (doubles on an fp limb): the column pass scales
     }
 }
 

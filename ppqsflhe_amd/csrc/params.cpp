@@ -207,6 +207,12 @@ void ParamSet::generate(uint32_t log_n_, uint32_t depth, uint32_t sbits, uint32_
         c.c64 = (u64)(((u128)1 << 64) % q);
         c.ninv = h_invmod(n % q, q);
         c.ninv_sh = h_shoup(c.ninv, q);
+        c.qd = (double)q;
+        c.qinv = (double)(1.0L / (long double)q);
+        c.ninv_d = (double)c.ninv;
+        c.ninv_qd = (double)((long double)c.ninv / (long double)q);
+        c.fp = 0;  // the engine decides (needs both passes on the radix kernels)
+        c.pad_ = 0;
     }
 
     // scaling factors (FLEXIBLEAUTOEXT): sf[0] = extra limb, sf[1] = q_{L-2}, then sf^2/q going down

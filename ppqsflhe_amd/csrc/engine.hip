@@ -443,6 +443,15 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
         tabs_.has_fp |= ps_.limb[i].fp;
     }
     tabs_.h_fp_of = fp_of_.data();
+    if (tabs_.has_fp) {
+        // measured on MI355X: forking the two instances onto two streams costs more (event round trips) than the
+        // overlapped tail waves return (-5 %), so it stays off unless asked for
+        const char *e = std::getenv("MKCKKS_TWO_LANES");
+        two_lanes_ = e && std::atoi(e) == 1;
+        MK_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
+        MK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        MK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    }
     MK_HIP(hipMalloc(&d_limb_, D * sizeof(LimbConst)));
     MK_HIP(hipMemcpy(d_limb_, ps_.limb.data(), D * sizeof(LimbConst), hipMemcpyHostToDevice));
     const size_t tbytes = (size_t)D * n * sizeof(u64);
@@ -498,6 +507,18 @@ Engine::~Engine() {
                     (void *)d_rot_, (void *)d_ksi_})
         if (p) (void)hipFree(p);
     for (void *p : owned_) (void)hipFree(p);
+    if (side_stream_) (void)hipStreamDestroy(side_stream_);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
+}
+
+Lanes Engine::lanes() const {
+    Lanes ln;
+    ln.main = stream_;
+    ln.side = two_lanes_ ? side_stream_ : nullptr;
+    ln.fork = ev_fork_;
+    ln.join = ev_join_;
+    return ln;
 }
 
 void Engine::need_device() const {
@@ -633,6 +654,23 @@ static int fast_log_h(uint32_t log_r, uint32_t other_extent) {
 }
 
 // pack != 0 (inverse radix kernels only): results leave as packed 30-bit halves for k_conv_col
+// The integer and the fp64 instance of a pass touch disjoint limbs: when both have work they are launched on two
+// streams (fork/join with events) so the partial last waves of one overlap the other.
+template <typename FInt, typename FFp>
+static void launch_two_classes(const Lanes &ln, bool has_int, bool has_fp, FInt &&launch_int, FFp &&launch_fp) {
+    if (has_int && has_fp && ln.side) {
+        MK_HIP(hipEventRecord(ln.fork, ln.main));
+        MK_HIP(hipStreamWaitEvent(ln.side, ln.fork, 0));
+        launch_int(ln.main);
+        launch_fp(ln.side);
+        MK_HIP(hipEventRecord(ln.join, ln.side));
+        MK_HIP(hipStreamWaitEvent(ln.main, ln.join, 0));
+    } else {
+        if (has_int) launch_int(ln.main);
+        if (has_fp) launch_fp(ln.main);
+    }
+}
+
 // slots of `io` whose limb runs on the fp64 (want_fp) or the integer instance; fp_of: per-limb-id class (host copy)
 static unsigned long long class_mask(const NttIo &io, const unsigned char *fp_of, uint32_t L, bool want_fp) {
     unsigned long long m = 0;
@@ -645,7 +683,7 @@ static unsigned long long class_mask(const NttIo &io, const unsigned char *fp_of
 
 template <bool INV>
 static void launch_col(const NttIo &io0, const NttTables &T, uint32_t n_polys, const u64 *scale, const u64 *scale_sh,
-                       hipStream_t s, int pack = 0) {
+                       const Lanes &ln, int pack = 0) {
     const uint32_t r1 = 1u << T.log_r1, r2 = 1u << T.log_r2;
     NttIo io = io0, iof = io0;
     io.slot_mask = class_mask(io0, T.h_fp_of, T.L, false);
@@ -655,20 +693,23 @@ static void launch_col(const NttIo &io0, const NttTables &T, uint32_t n_polys, c
     const uint32_t items = n_polys * io.nsel, itemsf = n_polys * iof.nsel;
     switch (fast_log_h(T.log_r1, r2)) {
         case 4:
-            if (items) k_ntt_col_r<4, INV, false><<<dim3(r2 / 16, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack);
-            if (itemsf) k_ntt_col_r<4, INV, true><<<dim3(r2 / 16, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack);
+            launch_two_classes(ln, items != 0, itemsf != 0,
+                [&](hipStream_t s) { k_ntt_col_r<4, INV, false><<<dim3(r2 / 16, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); },
+                [&](hipStream_t s) { k_ntt_col_r<4, INV, true><<<dim3(r2 / 16, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack); });
             break;
         case 3:
-            if (items) k_ntt_col_r<3, INV, false><<<dim3(r2 / 32, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack);
-            if (itemsf) k_ntt_col_r<3, INV, true><<<dim3(r2 / 32, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack);
+            launch_two_classes(ln, items != 0, itemsf != 0,
+                [&](hipStream_t s) { k_ntt_col_r<3, INV, false><<<dim3(r2 / 32, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); },
+                [&](hipStream_t s) { k_ntt_col_r<3, INV, true><<<dim3(r2 / 32, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack); });
             break;
         case 2:
-            if (items) k_ntt_col_r<2, INV, false><<<dim3(r2 / 64, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack);
-            if (itemsf) k_ntt_col_r<2, INV, true><<<dim3(r2 / 64, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack);
+            launch_two_classes(ln, items != 0, itemsf != 0,
+                [&](hipStream_t s) { k_ntt_col_r<2, INV, false><<<dim3(r2 / 64, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); },
+                [&](hipStream_t s) { k_ntt_col_r<2, INV, true><<<dim3(r2 / 64, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack); });
             break;
         default:
             if (pack) throw std::logic_error("packed output needs the radix column kernel");
-            k_ntt_col<INV><<<dim3(r2 / NTT_COLS, n_polys * io0.nslots), NTT_THREADS, (size_t)r1 * NTT_COLS * sizeof(u64), s>>>(
+            k_ntt_col<INV><<<dim3(r2 / NTT_COLS, n_polys * io0.nslots), NTT_THREADS, (size_t)r1 * NTT_COLS * sizeof(u64), ln.main>>>(
                 io0, T, scale, scale_sh);
     }
 }
@@ -676,7 +717,7 @@ static void launch_col(const NttIo &io0, const NttTables &T, uint32_t n_polys, c
 static bool row_tail_supported(const NttTables &T) { return fast_log_h(T.log_r2, 1u << T.log_r1) != 0; }
 
 template <bool INV>
-static void launch_row(const NttIo &io0, const NttTables &T, uint32_t n_polys, const TailArgs &tail, hipStream_t s) {
+static void launch_row(const NttIo &io0, const NttTables &T, uint32_t n_polys, const TailArgs &tail, const Lanes &ln) {
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     NttIo io = io0, iof = io0;
     io.slot_mask = class_mask(io0, T.h_fp_of, T.L, false);
@@ -686,28 +727,31 @@ static void launch_row(const NttIo &io0, const NttTables &T, uint32_t n_polys, c
     const uint32_t items = n_polys * io.nsel, itemsf = n_polys * iof.nsel;
     switch (fast_log_h(T.log_r2, r1)) {
         case 4:
-            if (items) k_ntt_row_r<4, INV, false><<<dim3((r1 / 16) * items), NTT_THREADS, 0, s>>>(io, T, tail);
-            if (itemsf) k_ntt_row_r<4, INV, true><<<dim3((r1 / 16) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail);
+            launch_two_classes(ln, items != 0, itemsf != 0,
+                [&](hipStream_t s) { k_ntt_row_r<4, INV, false><<<dim3((r1 / 16) * items), NTT_THREADS, 0, s>>>(io, T, tail); },
+                [&](hipStream_t s) { k_ntt_row_r<4, INV, true><<<dim3((r1 / 16) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
             break;
         case 3:
-            if (items) k_ntt_row_r<3, INV, false><<<dim3((r1 / 32) * items), NTT_THREADS, 0, s>>>(io, T, tail);
-            if (itemsf) k_ntt_row_r<3, INV, true><<<dim3((r1 / 32) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail);
+            launch_two_classes(ln, items != 0, itemsf != 0,
+                [&](hipStream_t s) { k_ntt_row_r<3, INV, false><<<dim3((r1 / 32) * items), NTT_THREADS, 0, s>>>(io, T, tail); },
+                [&](hipStream_t s) { k_ntt_row_r<3, INV, true><<<dim3((r1 / 32) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
             break;
         case 2:
-            if (items) k_ntt_row_r<2, INV, false><<<dim3((r1 / 64) * items), NTT_THREADS, 0, s>>>(io, T, tail);
-            if (itemsf) k_ntt_row_r<2, INV, true><<<dim3((r1 / 64) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail);
+            launch_two_classes(ln, items != 0, itemsf != 0,
+                [&](hipStream_t s) { k_ntt_row_r<2, INV, false><<<dim3((r1 / 64) * items), NTT_THREADS, 0, s>>>(io, T, tail); },
+                [&](hipStream_t s) { k_ntt_row_r<2, INV, true><<<dim3((r1 / 64) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
             break;
         default: {
             if (tail.enabled) throw std::logic_error("fused tail needs the radix row kernel");
             const uint32_t tile = n < (uint32_t)NTT_TILE ? n : (uint32_t)NTT_TILE;
-            k_ntt_row<INV><<<dim3(n / tile, n_polys * io0.nslots), NTT_THREADS, (size_t)tile * sizeof(u64), s>>>(io0, T);
+            k_ntt_row<INV><<<dim3(n / tile, n_polys * io0.nslots), NTT_THREADS, (size_t)tile * sizeof(u64), ln.main>>>(io0, T);
         }
     }
 }
 
 // two-pass launcher: reads `io.in`, leaves the result in `io.out` (may be the same buffer)
 static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inverse, const u64 *scale,
-                       const u64 *scale_sh, hipStream_t s, int pack = 0) {
+                       const u64 *scale_sh, const Lanes &s, int pack = 0) {
     if (n_polys == 0 || io.nslots == 0) return;
     NttIo second = io;  // second pass runs in place on the output
     second.in = io.out;
@@ -727,7 +771,7 @@ static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inve
 // base conversion fused into the forward column pass of every converted limb (k_conv_col); false when the
 // column pass of this ring size has no radix kernel (the caller then runs k_baseconv + a plain column pass)
 template <int LOG_H>
-static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, hipStream_t s) {
+static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, const Lanes &ln) {
     const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
     ConvIo io = io0, iof = io0;
     io.target_mask = iof.target_mask = 0;
@@ -738,41 +782,49 @@ static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevCo
     const dim3 grid(io.items * tiles * io.nsel), gridf(io.items * tiles * iof.nsel);
     switch (cv.n_in) {
         case 1:
-            if (io.nsel) k_conv_col<LOG_H, 1, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
-            if (iof.nsel) k_conv_col<LOG_H, 1, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
+                [&](hipStream_t s) { k_conv_col<LOG_H, 1, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
+                [&](hipStream_t s) { k_conv_col<LOG_H, 1, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
             break;
         case 2:
-            if (io.nsel) k_conv_col<LOG_H, 2, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
-            if (iof.nsel) k_conv_col<LOG_H, 2, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
+                [&](hipStream_t s) { k_conv_col<LOG_H, 2, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
+                [&](hipStream_t s) { k_conv_col<LOG_H, 2, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
             break;
         case 3:
-            if (io.nsel) k_conv_col<LOG_H, 3, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
-            if (iof.nsel) k_conv_col<LOG_H, 3, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
+                [&](hipStream_t s) { k_conv_col<LOG_H, 3, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
+                [&](hipStream_t s) { k_conv_col<LOG_H, 3, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
             break;
         case 4:
-            if (io.nsel) k_conv_col<LOG_H, 4, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
-            if (iof.nsel) k_conv_col<LOG_H, 4, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
+                [&](hipStream_t s) { k_conv_col<LOG_H, 4, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
+                [&](hipStream_t s) { k_conv_col<LOG_H, 4, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
             break;
         case 5:
-            if (io.nsel) k_conv_col<LOG_H, 5, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
-            if (iof.nsel) k_conv_col<LOG_H, 5, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
+                [&](hipStream_t s) { k_conv_col<LOG_H, 5, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
+                [&](hipStream_t s) { k_conv_col<LOG_H, 5, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
             break;
         case 6:
-            if (io.nsel) k_conv_col<LOG_H, 6, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
-            if (iof.nsel) k_conv_col<LOG_H, 6, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
+                [&](hipStream_t s) { k_conv_col<LOG_H, 6, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
+                [&](hipStream_t s) { k_conv_col<LOG_H, 6, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
             break;
         case 7:
-            if (io.nsel) k_conv_col<LOG_H, 7, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
-            if (iof.nsel) k_conv_col<LOG_H, 7, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
+                [&](hipStream_t s) { k_conv_col<LOG_H, 7, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
+                [&](hipStream_t s) { k_conv_col<LOG_H, 7, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
             break;
         case 8:
-            if (io.nsel) k_conv_col<LOG_H, 8, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
-            if (iof.nsel) k_conv_col<LOG_H, 8, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv);
+            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
+                [&](hipStream_t s) { k_conv_col<LOG_H, 8, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
+                [&](hipStream_t s) { k_conv_col<LOG_H, 8, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
             break;
         default: throw std::invalid_argument("base conversion fan-in unsupported");
     }
 }
-static bool launch_conv_col(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s) {
+static bool launch_conv_col(const ConvIo &io, const NttTables &T, const DevConv &cv, const Lanes &s) {
     switch (fast_log_h(T.log_r1, 1u << T.log_r2)) {
         case 4: launch_conv_col_h<4>(io, T, cv, s); break;
         case 3: launch_conv_col_h<3>(io, T, cv, s); break;
@@ -786,7 +838,7 @@ static bool launch_conv_col(const ConvIo &io, const NttTables &T, const DevConv 
 void Engine::ntt_launch(u64 *d, uint32_t n_polys, uint32_t nl, uint32_t ext, bool inverse, const u64 *scale,
                         const u64 *scale_sh) {
     NttIo io{d, d, (size_t)ext * ps_.n, (size_t)ext * ps_.n, 0, 0, 0, ext, nl};
-    ntt_passes(io, tabs_, n_polys, inverse, scale, scale_sh, stream_);
+    ntt_passes(io, tabs_, n_polys, inverse, scale, scale_sh, lanes());
 }
 
 void Engine::ntt_forward(u64 *d, uint32_t n_polys, uint32_t nl, bool with_p) {
@@ -866,7 +918,7 @@ void Engine::rescale(const u64 *in, u64 *out, uint32_t n_ct, uint32_t nl, const 
     MK_HIP(hipStreamSynchronize(stream_));
     // 1. dropped limb -> COEFFICIENT format
     NttIo io{in, d_last, (size_t)nl * n, (size_t)n, last, 0, last, 1, nl};
-    ntt_passes(io, tabs_, items, true, nullptr, nullptr, stream_);
+    ntt_passes(io, tabs_, items, true, nullptr, nullptr, lanes());
     // 2. centred switch of modulus into every remaining limb, 3. back to EVALUATION
     EwGeom g{n, nl, ps_.L};
     k_switch_modulus<<<ew_grid(n, last, items), EW_THREADS, 0, stream_>>>(d_last, d_tmp, g, d_limb_, ps_.moduli[last]);
@@ -929,17 +981,17 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
     bool fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0;
     // S1: c1 -> COEFFICIENT format, scaled by N^-1 * Qhat_inv
     NttIo s1{c1, coef, c1_stride, (size_t)nl * n, 0, 0, 0, nl, nl};
-    ntt_passes(s1, tabs_, cnt, true, fold, fold + D, stream_, fused ? 1 : 0);
+    ntt_passes(s1, tabs_, cnt, true, fold, fold + D, lanes(), fused ? 1 : 0);
     const size_t dstride = (size_t)nparts * ext * n;
     for (uint32_t part = 0; part < nparts && fused; ++part) {
         // S2+S3a: base conversion fused into the column pass of each complement limb
         ConvIo io{coef, dig + (size_t)part * ext * n, (size_t)nl * n, dstride, cnt, 0, 0};
-        launch_conv_col(io, tabs_, modup_conv(nl, part), stream_);
+        launch_conv_col(io, tabs_, modup_conv(nl, part), lanes());
     }
     if (fused) {
         // S3b: one row pass over every converted limb of every digit (own limbs skipped)
         NttIo row{dig, dig, (size_t)ext * n, (size_t)ext * n, 0, 0, 0, ext, nl, nparts, ps_.alpha};
-        launch_row<false>(row, tabs_, cnt * nparts, TailArgs{}, stream_);
+        launch_row<false>(row, tabs_, cnt * nparts, TailArgs{}, lanes());
         MK_HIP(hipGetLastError());
         return;
     }
@@ -950,11 +1002,11 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
         launch_baseconv(coef, (size_t)nl * n, d, dstride, cv, d_limb_, n, cnt, 1, stream_);
         if (lo > 0) {
             NttIo a{d, d, dstride, dstride, 0, 0, 0, lo, nl};
-            ntt_passes(a, tabs_, cnt, false, nullptr, nullptr, stream_);
+            ntt_passes(a, tabs_, cnt, false, nullptr, nullptr, lanes());
         }
         if (hi < ext) {
             NttIo b{d, d, dstride, dstride, hi, hi, hi, ext - hi, nl};
-            ntt_passes(b, tabs_, cnt, false, nullptr, nullptr, stream_);
+            ntt_passes(b, tabs_, cnt, false, nullptr, nullptr, lanes());
         }
     }
 }
@@ -967,16 +1019,16 @@ void Engine::moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t o
     const u64 *fold = folded_scale(nl), *pinv = p_inverse(nl);
     const bool fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0 && row_tail_supported(tabs_);
     NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
-    ntt_passes(s5, tabs_, cnt, true, fold, fold + D, stream_, fused ? 1 : 0);
+    ntt_passes(s5, tabs_, cnt, true, fold, fold + D, lanes(), fused ? 1 : 0);
     const DevConv &cv = moddown_conv(nl);
     ConvIo io{pc, conv, (size_t)K * n, (size_t)nl * n, cnt, 0, 0};
     EwGeom g{n, nl, ps_.L};
     if (fused) {
-        launch_conv_col(io, tabs_, cv, stream_);
+        launch_conv_col(io, tabs_, cv, lanes());
         // row pass of the converted limbs with the (ctilde_Q - conv) * P^-1 (+ c0) tail in its copy-out
         NttIo row{conv, out, (size_t)nl * n, out_stride, 0, 0, 0, nl, nl};
         TailArgs tail{til, add, pinv, pinv + nl, add_stride, ext, 1, accumulate ? 1u : 0u};
-        launch_row<false>(row, tabs_, cnt, tail, stream_);
+        launch_row<false>(row, tabs_, cnt, tail, lanes());
         MK_HIP(hipGetLastError());
         return;
     }

@@ -43,6 +43,12 @@ struct DevConv {
     const u64 *hat;  // device, [n_in][n_out]
 };
 
+// the stream pair a pass is launched on (integer instance on `main`, fp64 instance on `side` when both have work)
+struct Lanes {
+    hipStream_t main = nullptr, side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+
 class Engine {
 public:
     explicit Engine(const ParamSet &ps, int device);
@@ -95,6 +101,7 @@ public:
 
 private:
     void need_device() const;
+    Lanes lanes() const;
     void check_nl(uint32_t nl) const;
     u64 *workspace(size_t words);  // grow-only scratch arena (stream-ordered reuse)
     const DevConv &modup_conv(uint32_t nl, uint32_t part);
@@ -116,6 +123,9 @@ private:
     LimbConst *d_limb_ = nullptr;
     u64 *d_tw_ = nullptr, *d_tw_sh_ = nullptr, *d_itw_ = nullptr, *d_itw_sh_ = nullptr;
     std::vector<uint8_t> fp_of_;  // per limb id: 1 = fp64 kernel instance
+    hipStream_t side_stream_ = nullptr;  // second lane for the fp64 instances of a pass
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    bool two_lanes_ = false;
     uint32_t *d_rot_ = nullptr;
     void *d_ksi_ = nullptr;
     u64 *ws_ = nullptr;

@@ -17,6 +17,8 @@ CONFIGS = {
     "ref": (14, 2, 40, 60, 2),        # the reference's own CC.json
     "c3": (16, 10, 50, 60, 3),        # BASELINE configs[1..2]: N=2^16, L=12, dnum=3
     "c5s": (12, 18, 50, 60, 3),       # BASELINE configs[4] limb structure (L=20, alpha=7, K=7) at a small ring
+    "n17": (17, 2, 50, 60, 2),        # BASELINE configs[4] ring dimension (radix column pass + generic row pass)
+    "n11": (11, 2, 40, 60, 2),        # odd log N: generic kernels for both passes, integer arithmetic only
 }
 
 
@@ -283,7 +285,7 @@ def test_encode_decode_on_device(ctxs, name):
 
 @pytest.mark.parametrize("name,nl", [("tiny", 5), ("tiny", 4), ("tiny", 3), ("tiny", 1), ("c1", 3), ("c1", 2),
                                      ("ref", 4), ("ref", 3), ("c3", 12), ("c3", 11), ("c3", 5),
-                                     ("c5s", 20), ("c5s", 15), ("c5s", 8)])
+                                     ("c5s", 20), ("c5s", 15), ("c5s", 8), ("n17", 4), ("n11", 4), ("n11", 3)])
 def test_modup_moddown_reencrypt(ctxs, name, nl):
     g, o = ctxs(name)
     rng = np.random.default_rng(16)

@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--cts", type=int, default=16, help="ciphertexts per client (multiple of --gpus)")
     ap.add_argument("--cpu-sample", type=int, default=384, help="ciphertexts in the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--mode", choices=["sum", "accumulate"], default="sum",
+                    help="sum: one reencrypt_sum_batch call over all clients (last ModDown pass + aggregation fused); "
+                         "accumulate: per-client reencrypt_accumulate_batch calls spread over --streams")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the clients' PRE batches are spread over (each with its own context/workspace)")
     args = ap.parse_args()
@@ -154,7 +157,14 @@ def main():
     inv_n = 1.0 / (C * world)
     lanes = [(None, ctx)] + side
 
-    def step():
+    def step_sum():
+        ctx.reencrypt_sum(ct_in, evk, agg, C, B, L)
+        if world > 1:
+            reduce_partial_sums(agg, shard)
+            ctx.reduce_mod(shard, Bs, L, world)
+        ctx.rescale_mult_const(shard, out, Bs, L, inv_n)
+
+    def step_accumulate():
         main = torch.cuda.current_stream()
         for st, _ in side:
             st.wait_stream(main)
@@ -173,6 +183,8 @@ def main():
             reduce_partial_sums(agg, shard)
             ctx.reduce_mod(shard, Bs, L, world)
         ctx.rescale_mult_const(shard, out, Bs, L, inv_n)
+
+    step = step_sum if args.mode == "sum" else step_accumulate
 
     def fence():
         torch.cuda.synchronize()
@@ -219,7 +231,7 @@ def main():
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"C3+C4: {C} clients x {B} ct per GPU, N=2^{args.log_n}, L={L}, K={K}, dnum={args.dnum}: "
-                               "reencrypt_accumulate_batch (hybrid key-switch PRE folded into the aggregate) -> "
+                               + ("reencrypt_sum_batch (hybrid key-switch PRE of every client, last ModDown pass fused with the sum) -> " if args.mode == "sum" else "reencrypt_accumulate_batch (hybrid key-switch PRE folded into the aggregate) -> ")
                                + ("RCCL reduce_scatter(u64 sum)+reduce_mod -> " if world > 1 else "")
                                + "rescale_mult_const(1/n)",
                    "ring_dim": N, "limbs": L, "special_limbs": K, "dnum": args.dnum, "clients_per_gpu": C,

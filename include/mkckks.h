@@ -122,6 +122,13 @@ int mkckks_reencrypt_batch(mkckks_ctx *c, const uint64_t *d_ct, const uint64_t *
  * round trip of the re-encrypted ciphertext through HBM).  d_acc must not alias d_ct. */
 int mkckks_reencrypt_accumulate_batch(mkckks_ctx *c, const uint64_t *d_ct, const uint64_t *d_evk, uint64_t *d_acc,
                                       uint32_t n_ct, uint32_t nl);
+/* n-client form of the server loop (changeCipherDomain x n, then the EvalAdd chain of
+ * aggregateEncryptedWeights.cpp:82): d_out[b] = sum_c ReEncrypt(d_cts[c][b], d_evks[c]) coefficient-wise mod q_i.
+ * d_cts u64[n_clients][n_ct][2][nl][N], d_evks u64[n_clients][beta][2][D][N] (one re-encryption key per client,
+ * all towards the common domain), d_out u64[n_ct][2][nl][N].  Bit-identical to re-encrypting every ciphertext and
+ * adding them in any order; the last ModDown pass of all clients and the sum are one kernel. */
+int mkckks_reencrypt_sum_batch(mkckks_ctx *c, const uint64_t *d_cts, const uint64_t *d_evks, uint64_t *d_out,
+                               uint32_t n_clients, uint32_t n_ct, uint32_t nl);
 /* stages of the above, exposed for parity tests and profiling:
  * KeySwitchHYBRID::EvalKeySwitchPrecomputeCore: c1 u64[n][nl][N] ->
  * digits u64[n][nparts][nl+K][N]; ApproxModDown: u64[n][nl+K][N] -> u64[n][nl][N]. */

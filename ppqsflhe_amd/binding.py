@@ -61,6 +61,7 @@ SYMBOLS = {
     "mkckks_mult_const_batch": (_int, [_vp, _vp, _u32, _u32, _dbl]),
     "mkckks_reencrypt_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32]),
     "mkckks_reencrypt_accumulate_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32]),
+    "mkckks_reencrypt_sum_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32]),
     "mkckks_modup_batch": (_int, [_vp, _vp, _vp, _u32, _u32]),
     "mkckks_moddown_batch": (_int, [_vp, _vp, _vp, _u32, _u32]),
     "mkckks_keygen": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
@@ -261,6 +262,9 @@ class Context:
 
     def reencrypt_accumulate(self, ct, evk, acc, n_ct, nl):
         self._check(self._L.mkckks_reencrypt_accumulate_batch(self._h, _ptr(ct), _ptr(evk), _ptr(acc), n_ct, nl))
+
+    def reencrypt_sum(self, cts, evks, out, n_clients, n_ct, nl):
+        self._check(self._L.mkckks_reencrypt_sum_batch(self._h, _ptr(cts), _ptr(evks), _ptr(out), n_clients, n_ct, nl))
 
     def modup(self, c1, digits, n, nl):
         self._check(self._L.mkckks_modup_batch(self._h, _ptr(c1), _ptr(digits), n, nl))

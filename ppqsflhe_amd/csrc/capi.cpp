@@ -219,6 +219,13 @@ int mkckks_reencrypt_accumulate_batch(mkckks_ctx *c, const uint64_t *ct, const u
         c->eng->reencrypt(ct, evk, acc, n_ct, nl, true);
     });
 }
+int mkckks_reencrypt_sum_batch(mkckks_ctx *c, const uint64_t *cts, const uint64_t *evks, uint64_t *out, uint32_t n_clients,
+                               uint32_t n_ct, uint32_t nl) {
+    return guarded([&] {
+        need(c && cts && evks && out, "null argument");
+        c->eng->reencrypt_sum(cts, evks, out, n_clients, n_ct, nl);
+    });
+}
 int mkckks_modup_batch(mkckks_ctx *c, const uint64_t *c1, uint64_t *digits, uint32_t n, uint32_t nl) {
     return guarded([&] {
         need(c && c1 && digits, "null argument");

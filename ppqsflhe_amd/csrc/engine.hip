@@ -443,7 +443,7 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
         tabs_.has_fp |= ps_.limb[i].fp;
     }
     tabs_.h_fp_of = fp_of_.data();
-    if (tabs_.has_fp) {
+    {
         // measured on MI355X: forking the two instances onto two streams costs more (event round trips) than the
         // overlapped tail waves return (-5 %), so it stays off unless asked for
         const char *e = std::getenv("MKCKKS_TWO_LANES");
@@ -1099,6 +1099,90 @@ void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t c
     MK_HIP(hipGetLastError());
     // S5: ApproxModDown of both components (2*cnt polynomials of ext limbs), + c0 on component 0
     moddown_core(til, pc, conv, out, (size_t)nl * n, ct, ct_stride, 2 * cnt, nl, accumulate);
+}
+
+template <int LOG_H>
+static void launch_row_tail_sum(SumArgs a, const NttTables &T, uint32_t L, hipStream_t s) {
+    const uint32_t tiles = (1u << T.log_r1) / (256u >> LOG_H);
+    SumArgs ai = a, af = a;
+    ai.slot_mask = af.slot_mask = 0;
+    for (uint32_t i = 0; i < a.nl; ++i) (T.h_fp_of[i] ? af.slot_mask : ai.slot_mask) |= 1ull << i;
+    ai.nsel = (uint32_t)__builtin_popcountll(ai.slot_mask);
+    af.nsel = (uint32_t)__builtin_popcountll(af.slot_mask);
+    (void)L;
+    if (ai.nsel) k_row_tail_sum<LOG_H, false><<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s>>>(ai, T);
+    if (af.nsel) k_row_tail_sum<LOG_H, true><<<dim3(tiles * af.nsel * a.n_polys), NTT_THREADS, 0, s>>>(af, T);
+}
+
+// sum over clients of ReEncrypt(ct_c[b], evk_c): everything up to the column pass of ModDown runs per client (two
+// clients in flight on two streams), the last row pass + tail + sum is one kernel over all clients.
+void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n_clients, uint32_t n_ct, uint32_t nl) {
+    need_device();
+    check_nl(nl);
+    if (!n_clients || !n_ct) return;
+    const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, nparts = ps_.num_parts(nl), D = ps_.D;
+    const size_t ct_words = (size_t)2 * nl * n, evk_words = (size_t)ps_.beta * 2 * D * n;
+    const bool fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0 && row_tail_supported(tabs_);
+    if (!fused) {  // ring sizes without radix kernels: plain loop with the accumulating tail
+        for (uint32_t c = 0; c < n_clients; ++c)
+            reencrypt(cts + (size_t)c * n_ct * ct_words, evks + (size_t)c * evk_words, out, n_ct, nl, c != 0);
+        return;
+    }
+    const u64 *fold = folded_scale(nl), *pinv = p_inverse(nl);
+    const int log_h = fast_log_h(tabs_.log_r2, 1u << tabs_.log_r1);
+    for (uint32_t b0 = 0; b0 < n_ct; b0 += chunk_) {
+        const uint32_t cnt = n_ct - b0 < chunk_ ? n_ct - b0 : chunk_;
+        // arena: per client {til, conv}; per lane {coef, dig, pc}
+        const size_t w_til = (size_t)cnt * 2 * ext * n, w_conv = (size_t)cnt * 2 * nl * n;
+        const size_t w_coef = (size_t)cnt * nl * n, w_dig = (size_t)cnt * nparts * ext * n, w_pc = (size_t)cnt * 2 * K * n;
+        const size_t w_lane = w_coef + w_dig + w_pc;
+        const bool two = side_stream_ != nullptr && n_clients > 1;
+        u64 *ws = workspace((size_t)n_clients * (w_til + w_conv) + (two ? 2 : 1) * w_lane);
+        u64 *til0 = ws, *conv0 = til0 + (size_t)n_clients * w_til, *lane0 = conv0 + (size_t)n_clients * w_conv;
+        hipStream_t main = stream_;
+        if (two) {
+            MK_HIP(hipEventRecord(ev_fork_, main));
+            MK_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
+        }
+        for (uint32_t c = 0; c < n_clients; ++c) {
+            const uint32_t lane = two ? (c & 1) : 0;
+            stream_ = lane ? side_stream_ : main;  // the helpers below launch on stream_
+            u64 *coef = lane0 + (size_t)lane * w_lane, *dig = coef + w_coef, *pc = dig + w_dig;
+            u64 *til = til0 + (size_t)c * w_til, *conv = conv0 + (size_t)c * w_conv;
+            const u64 *ct = cts + ((size_t)c * n_ct + b0) * ct_words, *evk = evks + (size_t)c * evk_words;
+            const u64 *c1 = ct + (size_t)nl * n;
+            modup_core(c1, ct_words, coef, dig, cnt, nl);
+            EwGeom g{n, nl, ps_.L};
+            switch (nparts) {
+                case 1: launch_inner<1>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
+                case 2: launch_inner<2>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
+                case 3: launch_inner<3>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
+                case 4: launch_inner<4>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
+                case 5: launch_inner<5>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
+                case 6: launch_inner<6>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
+                default: stream_ = main; throw std::invalid_argument("more than 6 key-switch digits unsupported");
+            }
+            MK_HIP(hipGetLastError());
+            // ModDown up to the column pass of the converted limbs
+            NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
+            ntt_passes(s5, tabs_, 2 * cnt, true, fold, fold + D, lanes(), 1);
+            ConvIo io{pc, conv, (size_t)K * n, (size_t)nl * n, 2 * cnt, 0, 0};
+            launch_conv_col(io, tabs_, moddown_conv(nl), lanes());
+        }
+        stream_ = main;
+        if (two) {
+            MK_HIP(hipEventRecord(ev_join_, side_stream_));
+            MK_HIP(hipStreamWaitEvent(main, ev_join_, 0));
+        }
+        SumArgs a{conv0, til0, cts + (size_t)b0 * ct_words, out + (size_t)b0 * ct_words, pinv, pinv + nl,
+                  w_conv, w_til, (size_t)n_ct * ct_words, ct_words, n_clients, nl, ext, 2 * cnt, 0, 0};
+        switch (log_h) {
+            case 4: launch_row_tail_sum<4>(a, tabs_, ps_.L, main); break;
+            case 3: launch_row_tail_sum<3>(a, tabs_, ps_.L, main); break;
+            default: launch_row_tail_sum<2>(a, tabs_, ps_.L, main); break;
+        }
+        MK_HIP(hipGetLastError());
+    }
 }
 
 void Engine::reencrypt(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl, bool accumulate) {

@@ -77,6 +77,8 @@ public:
     void mult_const(u64 *ct, uint32_t n_ct, uint32_t nl, const std::vector<u64> &factors);
     void reduce_mod(u64 *ct, uint32_t n_ct, uint32_t nl, uint32_t n_terms);
 
+    // out[b] = sum over clients of ReEncrypt(cts[c][b], evks[c]); cts [C][n_ct][2][nl][N], evks [C][beta][2][D][N]
+    void reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n_clients, uint32_t n_ct, uint32_t nl);
     void modup(const u64 *c1, u64 *digits, uint32_t n, uint32_t nl);
     void moddown(const u64 *in, u64 *out, uint32_t n, uint32_t nl);
     // accumulate: out[b] += ReEncrypt(ct[b]) (coefficient-wise, mod q) -- the fold into a running aggregate

@@ -450,4 +450,97 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
     }
 }
 
+// ModDown row pass + tail + aggregation over clients in ONE kernel: for a (ciphertext, component, limb, row tile)
+// the workgroup walks the n_clients converted polynomials, finishes each one's forward transform, applies the
+// ApproxModDown tail (ctilde_Q - conv) * P^-1 (+ c0 on component 0) and keeps the running coefficient-wise sum
+// in registers; the aggregate is written once instead of being read and re-written per client
+// (ReEncrypt x n_clients + EvalAdd x (n_clients - 1) of aggregateEncryptedWeights.cpp:82, one output stream).
+struct SumArgs {
+    const u64 *conv;     // [client][poly][nl][N]  column-passed converted limbs (lazy / doubles)
+    const u64 *til;      // [client][poly][ext][N] key-switch accumulators over Q_l P
+    const u64 *cts;      // [client][ct][2][nl][N] input ciphertexts (c0 added on component 0)
+    u64 *out;            // [poly][nl][N] = [ct][2][nl][N]
+    const u64 *pinv, *pinv_sh;
+    size_t conv_cstride, til_cstride, ct_cstride;  // words between clients
+    size_t ct_stride;    // words between ciphertexts of one client in `cts`
+    uint32_t n_clients, nl, ext, n_polys;
+    unsigned long long slot_mask;
+    uint32_t nsel;
+};
+template <int LOG_H, bool FP>
+__global__ __launch_bounds__(NTT_THREADS, 4) void k_row_tail_sum(SumArgs a, NttTables T) {
+    using TL = RowTile<LOG_H>;
+    using TA = RowTwA<LOG_H>;
+    constexpr int H = TL::H, S = TL::S, R = TL::R, PAIRS = S * R / 2 / NTT_THREADS;
+    __shared__ u64 lds[TL::WORDS + 2 * TA::WORDS];
+    u64 *twa = lds + TL::WORDS, *twa_sh = twa + TA::WORDS;
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
+    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
+    uint32_t grp, poly;
+    if (groups % 8 == 0) {
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / a.n_polys) * 8 + xcd;
+        poly = qidx % a.n_polys;
+    } else {
+        grp = blockIdx.x / a.n_polys;
+        poly = blockIdx.x % a.n_polys;
+    }
+    const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);  // Q limb: slot == limb id
+    const LimbConst lc = T.limb[sl];
+    if ((lc.fp != 0) != FP) return;
+    const uint32_t row0 = (grp % tiles) * S;
+    const int g = threadIdx.x / H, j = threadIdx.x % H;
+    const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
+    const uint32_t base = r1 + row0 + g;
+    const u64 pi = a.pinv[sl], pi_sh = a.pinv_sh[sl];
+    const size_t tile_off = (size_t)row0 * R;
+    TA::stage(twa, twa_sh, tw, tw_sh, r1 + row0);  // round-A twiddles are the same for every client
+    ulong2 acc[PAIRS];
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) acc[i] = ulong2{0, 0};
+    for (uint32_t c = 0; c < a.n_clients; ++c) {
+        const u64 *src = a.conv + (size_t)c * a.conv_cstride + ((size_t)poly * a.nl + sl) * n + tile_off;
+        u64 x[H], w[H - 1], wp[H - 1];
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = src[(size_t)g * R + j + H * k];
+        __syncthreads();  // twiddles staged (first client) / previous client's copy-out finished reading LDS
+        TA::fetch(twa, twa_sh, g, w, wp);
+        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
+        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);
+        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+#pragma unroll
+        for (int k = 0; k < H; ++k)
+            lds[TL::at(g, H * j + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
+        __syncthreads();
+        const u64 *tq = a.til + (size_t)c * a.til_cstride + ((size_t)poly * a.ext + sl) * n + tile_off;
+        const u64 *c0 = (poly & 1) == 0
+                            ? a.cts + (size_t)c * a.ct_cstride + (size_t)(poly >> 1) * a.ct_stride + (size_t)sl * n + tile_off
+                            : nullptr;
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = threadIdx.x + i * NTT_THREADS;
+            const int gg = (2 * e) / R, xx = (2 * e) % R;
+            const ulong2 t = reinterpret_cast<const ulong2 *>(tq)[e];
+            ulong2 v;
+            v.x = shoup_mul(sub_mod(t.x, lds[TL::at(gg, xx)], lc.q), pi, pi_sh, lc.q);
+            v.y = shoup_mul(sub_mod(t.y, lds[TL::at(gg, xx + 1)], lc.q), pi, pi_sh, lc.q);
+            if (c0) {
+                const ulong2 z = reinterpret_cast<const ulong2 *>(c0)[e];
+                v.x = add_mod(v.x, z.x, lc.q);
+                v.y = add_mod(v.y, z.y, lc.q);
+            }
+            acc[i].x = add_mod(acc[i].x, v.x, lc.q);
+            acc[i].y = add_mod(acc[i].y, v.y, lc.q);
+        }
+    }
+    u64 *dst = a.out + ((size_t)poly * a.nl + sl) * n + tile_off;
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[threadIdx.x + i * NTT_THREADS] = acc[i];
+}
+
 }  // namespace mk

@@ -347,6 +347,31 @@ def test_reencrypt_accumulate(ctxs, name, nl):
         g.reencrypt_accumulate(d_acc, g.to_device(evks[0]), d_acc, B, nl)  # aliasing is refused
 
 
+@pytest.mark.parametrize("name,nl,C,B", [("tiny", 5, 3, 2), ("tiny", 3, 1, 1), ("ref", 4, 2, 3), ("c3", 12, 3, 2),
+                                         ("c5s", 20, 2, 1), ("n11", 4, 3, 2), ("tiny", 5, 2, 19)])
+def test_reencrypt_sum(ctxs, name, nl, C, B):
+    # sum over clients of ReEncrypt(ct_c, evk_c) in one call == EvalAdd chain of the individual re-encryptions
+    g, o = ctxs(name)
+    rng = np.random.default_rng(23)
+    cts = np.stack([rand_ct(rng, g, nl, B) for _ in range(C)])
+    evks = np.stack([rand_polys(rng, g, list(range(g.D)) * (2 * g.beta), 1).reshape(g.beta, 2, g.D, g.N)
+                     for _ in range(C)])
+    d_out = g.empty((B, 2, nl, g.N))
+    g.reencrypt_sum(g.to_device(cts), g.to_device(evks), d_out, C, B, nl)
+    got = d_out.to_host()
+    for b in range(B if B < 4 else 3):
+        acc = o.reencrypt(cts[0, b], evks[0])
+        for c in range(1, C):
+            acc = o.eval_add(acc, o.reencrypt(cts[c, b], evks[c]))
+        assert np.array_equal(got[b], acc), (name, nl, b)
+    if B >= 4:  # spot-check the last chunk too
+        b = B - 1
+        acc = o.reencrypt(cts[0, b], evks[0])
+        for c in range(1, C):
+            acc = o.eval_add(acc, o.reencrypt(cts[c, b], evks[c]))
+        assert np.array_equal(got[b], acc)
+
+
 def test_device_samplers(ctxs):
     """Philox samplers in HBM: distributional checks (OpenFHE's PRNG stream is not reproducible), determinism per
     (seed, stream), independence across streams, exact range of the uniform limbs."""

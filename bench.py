@@ -239,7 +239,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_unit": bytes_unit, "units_per_launch": C * B,
-                     "launch": "one hot-path step on one GPU (all kernels of the path, one stream)",
+                     "launch": "one hot-path step on one GPU (all kernels of the path)",
                      "launch_ms": step_s_gpu * 1e3, "frac_of_measured_copy_peak": achieved / HBM_MEASURED_GBS},
     }
     if rank == 0 and world == 1 and not args.no_cpu:

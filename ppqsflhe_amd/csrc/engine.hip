@@ -1140,6 +1140,10 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
         u64 *ws = workspace((size_t)n_clients * (w_til + w_conv) + (two ? 2 : 1) * w_lane);
         u64 *til0 = ws, *conv0 = til0 + (size_t)n_clients * w_til, *lane0 = conv0 + (size_t)n_clients * w_conv;
         hipStream_t main = stream_;
+        struct Restore {  // the per-client helpers launch on stream_; put it back on every exit path
+            hipStream_t &ref, saved;
+            ~Restore() { ref = saved; }
+        } restore{stream_, main};
         if (two) {
             MK_HIP(hipEventRecord(ev_fork_, main));
             MK_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
@@ -1160,7 +1164,7 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
                 case 4: launch_inner<4>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
                 case 5: launch_inner<5>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
                 case 6: launch_inner<6>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
-                default: stream_ = main; throw std::invalid_argument("more than 6 key-switch digits unsupported");
+                default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
             }
             MK_HIP(hipGetLastError());
             // ModDown up to the column pass of the converted limbs

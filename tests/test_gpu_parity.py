@@ -492,3 +492,73 @@ def test_errors_are_loud(ctxs):
         g.rescale(d, d, 1, 1)
     with pytest.raises(MkckksError):
         g.reduce_mod(d, 1, g.L, 9)
+
+
+def test_config5_full_round_n17_l20():
+    """BASELINE configs[4] shape: N=2^17, L=20 limbs, dnum=3 (alpha=7, K=7), ~1e5 weights packed into 2 ciphertexts
+    per client, 2 clients: encode+encrypt -> PRE -> aggregate -> PRE back -> decrypt+decode, all on the GPU; key
+    switching bit-exact vs the oracle on one ciphertext, decoded result within 2^-25 of the plaintext mean."""
+    from ppqsflhe_amd import Context
+    g = Context(17, 18, 50, 60, dnum=3, device=0)
+    o = OracleContext(17, 18, 50, 60, dnum=3)
+    assert (g.L, g.K, g.alpha, g.beta) == (20, 7, 7, 3)
+    rng = np.random.default_rng(24)
+    N, L, D, slots = g.N, g.L, g.D, g.N // 2
+    n_w = 100_000
+    B = -(-n_w // slots)  # 2 ciphertexts of 65536 slots
+    w = [rng.uniform(-0.3, 0.3, size=n_w) for _ in range(2)]
+
+    def device_keys(seed):
+        d_s, d_e, d_a = g.empty((N,), np.int8), g.empty((N,), np.int32), g.empty((D, N))
+        g.sample_ternary(d_s, N, seed, 0)
+        g.sample_gauss(d_e, N, 3.19, seed, 1)
+        g.sample_uniform(d_a, 1, L, True, seed, 2)
+        d_pk, d_sk = g.empty((2, D, N)), g.empty((D, N))
+        g.keygen(d_s, d_a, d_e, d_pk, d_sk)
+        return d_s, d_pk, d_sk
+
+    k1, k2 = device_keys(1), device_keys(2)
+
+    def device_rekey(sk_t, pk_new, seed):
+        d_u, d_e0, d_e1 = g.empty((g.beta, N), np.int8), g.empty((g.beta, N), np.int32), g.empty((g.beta, N), np.int32)
+        g.sample_ternary(d_u, g.beta * N, seed, 0)
+        g.sample_gauss(d_e0, g.beta * N, 3.19, seed, 1)
+        g.sample_gauss(d_e1, g.beta * N, 3.19, seed, 2)
+        d_evk = g.empty((g.beta, 2, D, N))
+        g.rekeygen(sk_t, pk_new, d_u, d_e0, d_e1, d_evk)
+        return d_evk
+
+    rk12, rk21 = device_rekey(k1[0], k2[1], 11), device_rekey(k2[0], k1[1], 12)
+    scale = g.sf_big(0)
+
+    def device_encrypt(pk, vals, seed):
+        padded = np.zeros((B, slots))
+        padded.reshape(-1)[:n_w] = vals
+        d_pt, d_ct = g.empty((B, L, N)), g.empty((B, 2, L, N))
+        g.encode(g.to_device(padded), d_pt, B, L, scale)
+        d_v, d_e0, d_e1 = g.empty((B, N), np.int8), g.empty((B, N), np.int32), g.empty((B, N), np.int32)
+        g.sample_ternary(d_v, B * N, seed, 0)
+        g.sample_gauss(d_e0, B * N, 3.19, seed, 1)
+        g.sample_gauss(d_e1, B * N, 3.19, seed, 2)
+        g.encrypt(pk, d_pt, d_v, d_e0, d_e1, d_ct, B, L)
+        return d_ct
+
+    ct1, ct2 = device_encrypt(k1[1], w[0], 21), device_encrypt(k2[1], w[1], 22)
+    d12 = g.empty((B, 2, L, N))
+    g.reencrypt(ct1, rk12, d12, B, L)
+    # bit-exact key switch vs the oracle on the first ciphertext at full size
+    assert np.array_equal(d12.to_host()[0], o.reencrypt(ct1.to_host()[0], rk12.to_host()))
+    d_sum, d_avg = g.empty((B, 2, L, N)), g.empty((B, 2, L - 1, N))
+    g.eval_add(d12, ct2, d_sum, B, L)
+    g.rescale_mult_const(d_sum, d_avg, B, L, 0.5)
+    d_back = g.empty((B, 2, L - 1, N))
+    g.reencrypt(d_avg, rk21, d_back, B, L - 1)
+    out_scale = g.sf(1) ** 2
+    mean = (w[0] + w[1]) / 2
+    for d_ct, sk in ((d_avg, k2[2]), (d_back, k1[2])):
+        d_m, d_vals = g.empty((B, L - 1, N)), g.empty((B, slots), np.float64)
+        g.decrypt(d_ct, sk, d_m, B, L - 1)
+        g.decode(d_m, d_vals, B, L - 1, out_scale)
+        got = d_vals.to_host().reshape(-1)[:n_w]
+        assert np.abs(got - mean).max() < 2.0 ** -25
+    g.close()

@@ -110,6 +110,7 @@ def test_full_round_through_the_binaries(tmp_path, golden_dir):
             layers.append({"layer": m["layer"], "shape": shape, "mean": float(ms[0]), "std_dev": float(ms[1]),
                            "values": [float(v) for v in vals]})
         layers.append({"layer": "optimizer/iteration", "shape": [1], "mean": 1.0, "std_dev": 0.0, "values": [3.0]})
+        layers.append({"layer": "empty_tensor", "shape": [0], "mean": 0.0, "std_dev": 0.0, "values": []})  # edge: no values
         p = tmp_path / f"sample_weights_c{c}.json"
         p.write_text(json.dumps({"weights_summary": layers}))
         return p
@@ -131,7 +132,8 @@ def test_full_round_through_the_binaries(tmp_path, golden_dir):
         assert "Skipping optimizer layer: optimizer/iteration" in r.stdout
         assert "Batch size from CryptoContext = 8192" in r.stdout
     enc1 = json.load(open(tmp_path / "enc1.json"))
-    assert [l["layer"] for l in enc1["weights_summary"]] == [m["layer"] for m in keep]
+    assert [l["layer"] for l in enc1["weights_summary"]] == [m["layer"] for m in keep] + ["empty_tensor"]
+    assert enc1["weights_summary"][-1]["values"] == []
     assert all(isinstance(l["mean"], str) and isinstance(l["values"], list) for l in enc1["weights_summary"])
     r = ok(run("changeCipherDomain", cc, tmp_path / "rk1", tmp_path / "enc1.json", tmp_path / "c1_as_c2.json"))
     assert "[recrypt] Re-encryption completed successfully" in r.stdout
@@ -146,8 +148,9 @@ def test_full_round_through_the_binaries(tmp_path, golden_dir):
     tol = 2.0 ** -25
     for c in (1, 2):
         dec = json.load(open(tmp_path / f"dec{c}.json"))["weights_summary"]
-        assert [l["layer"] for l in dec] == [m["layer"] for m in keep]
-        for l in dec:
+        assert [l["layer"] for l in dec] == [m["layer"] for m in keep] + ["empty_tensor"]
+        assert dec[-1]["values"] == [] and abs(dec[-1]["mean"]) < tol
+        for l in dec[:-1]:
             name = l["layer"]
             v1, v2 = W[f"sample_c1_{name}_values"], W[f"sample_c2_{name}_values"]
             got = np.array(l["values"])

@@ -562,3 +562,53 @@ def test_config5_full_round_n17_l20():
         got = d_vals.to_host().reshape(-1)[:n_w]
         assert np.abs(got - mean).max() < 2.0 ** -25
     g.close()
+
+
+def test_full_size_batch_properties(ctxs):
+    """BASELINE configs[1..3] at full batch size (8 clients x 16 ciphertexts, N=2^16, L=12), checked through
+    size-independent properties instead of the (slow) oracle: (a) an element of a large batch equals the same
+    ciphertext re-encrypted alone (batches only amortise, they never mix items); (b) the fused n-client kernel path
+    equals re-encrypt-each-then-add (different kernels, same bits); (c) the accumulate form equals both; (d) the
+    u64-sum + reduce_mod collective arithmetic equals eval_sum."""
+    import torch
+    g, _ = ctxs("c3")
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    C, B, L, N, D = 8, 16, g.L, g.N, g.D
+
+    def uniform(lead, ids):
+        t = torch.empty(*lead, len(ids), N, dtype=torch.int64, device=dev)
+        for j, l in enumerate(ids):
+            t[..., j, :] = torch.randint(0, int(g.moduli[l]), (*lead, N), generator=gen, device=dev, dtype=torch.int64)
+        return t
+
+    cts = uniform((C, B), list(range(L)) * 2).view(C, B, 2, L, N)
+    evks = uniform((C,), list(range(D)) * (2 * g.beta)).view(C, g.beta, 2, D, N)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    each = torch.empty_like(cts)
+    for c in range(C):
+        g.reencrypt(cts[c], evks[c], each[c], B, L)
+    # (a) singles vs batch
+    single = torch.empty(1, 2, L, N, dtype=torch.int64, device=dev)
+    for c, b in ((0, 0), (3, 7), (7, 15)):
+        g.reencrypt(cts[c, b:b + 1], evks[c], single, 1, L)
+        assert torch.equal(single[0], each[c, b])
+    # (b) fused sum vs add of the individual results
+    ref = torch.empty(B, 2, L, N, dtype=torch.int64, device=dev)
+    g.eval_sum(each, ref, C, B, L)
+    fused = torch.empty_like(ref)
+    g.reencrypt_sum(cts, evks, fused, C, B, L)
+    assert torch.equal(fused, ref)
+    # (c) accumulate form
+    acc = torch.empty_like(ref)
+    g.reencrypt(cts[0], evks[0], acc, B, L)
+    for c in range(1, C):
+        g.reencrypt_accumulate(cts[c], evks[c], acc, B, L)
+    assert torch.equal(acc, ref)
+    # (d) integer-sum collective arithmetic: wrap-around int64 sum of 8 canonical terms, then reduce_mod
+    raw = each.sum(dim=0)  # int64 wrap == uint64 add
+    g.reduce_mod(raw, B, L, C)
+    assert torch.equal(raw, ref)
+    torch.cuda.synchronize()
+    g.set_stream(None)

@@ -1136,7 +1136,10 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
         const size_t w_til = (size_t)cnt * 2 * ext * n, w_conv = (size_t)cnt * 2 * nl * n;
         const size_t w_coef = (size_t)cnt * nl * n, w_dig = (size_t)cnt * nparts * ext * n, w_pc = (size_t)cnt * 2 * K * n;
         const size_t w_lane = w_coef + w_dig + w_pc;
-        const bool two = side_stream_ != nullptr && n_clients > 1;
+        // two clients in flight on two streams (MKCKKS_SUM_ONE_LANE=1 serialises them, e.g. to compare the HIP-event
+        // step time with the sum of rocprof kernel durations)
+        static const bool one_lane = [] { const char *e = std::getenv("MKCKKS_SUM_ONE_LANE"); return e && std::atoi(e) == 1; }();
+        const bool two = side_stream_ != nullptr && n_clients > 1 && !one_lane;
         u64 *ws = workspace((size_t)n_clients * (w_til + w_conv) + (two ? 2 : 1) * w_lane);
         u64 *til0 = ws, *conv0 = til0 + (size_t)n_clients * w_til, *lane0 = conv0 + (size_t)n_clients * w_conv;
         hipStream_t main = stream_;

@@ -93,6 +93,13 @@ def load_library():
             raise ImportError(
                 f"{_LIB} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C ppqsflhe_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm ships its own libamdhip64: when both end up in one process the FIRST HIP runtime loaded owns
+        # the device and the other reports "no ROCm-capable device".  Tensors from torch are this binding's device
+        # buffers (bench.py, multi-GPU), so let torch load first whenever it is installed.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(_LIB)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # load torch's HIP runtime before libmkckks_hip.so (see ppqsflhe_amd/binding.py: load_library)
+    import torch  # noqa: F401
+except Exception:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

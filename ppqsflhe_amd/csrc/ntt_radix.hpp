@@ -68,12 +68,20 @@ MK_D void radix_inverse(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], 
 }
 
 // ---- fp64 rounds (limbs with LimbConst::fp): x[], w[], wq[] hold DOUBLE bit patterns -----------------
-// forward: u = reduce(x) (|u| <= 0.51q), v = y*w mod q (|v| <= q(0.5 + 1.0001|y|/2^52)); with q < 1.25*2^50 the
-// fixed point of the bound is |value| <= 1.47q.  inverse: s = x + y is reduced, d = x - y goes straight into the
+// forward: v = y*w mod q (|v| <= q(0.5 + 1.0001|y|/2^52)); x is re-centred (u = reduce(x), |u| <= 0.51q) on the even
+// stages of a round only; with q < 1.25*2^50 every value stays below 3.1q.  inverse: s = x + y is reduced, d = x - y goes straight into the
 // product (|d| <= 2.66q < 2^52.1, product output <= 1.33q).  Everything stays an exact integer below 2^53.
 MK_D void ct_butterfly_fp(u64 &xb, u64 &yb, u64 wb, u64 wqb, double q, double qinv) {
     const double v = fp_mulmod(bitsd(yb), bitsd(wb), bitsd(wqb), q);
     const double u = fp_reduce(bitsd(xb), q, qinv);
+    xb = dbits(u + v);
+    yb = dbits(u - v);
+}
+// forward butterfly without re-centring x (odd stages): with q < 1.25*2^50 the bound X -> 1.31 X + 0.5q after such a
+// stage and X -> 1.01q + 0.31 X after a re-centring one settle below 3.1q < 2^52, sums stay exact integers < 2^53
+MK_D void ct_butterfly_fp_nr(u64 &xb, u64 &yb, u64 wb, u64 wqb, double q) {
+    const double v = fp_mulmod(bitsd(yb), bitsd(wb), bitsd(wqb), q);
+    const double u = bitsd(xb);
     xb = dbits(u + v);
     yb = dbits(u - v);
 }
@@ -92,7 +100,8 @@ MK_D void radix_forward_fp(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1
 #pragma unroll
         for (int p = 0; p < H / 2; ++p) {
             const int g = p / dist, k0 = g * 2 * dist + (p % dist);
-            ct_butterfly_fp(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wq[(1 << s) - 1 + g], q, qinv);
+            if (s % 2 == 0) ct_butterfly_fp(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wq[(1 << s) - 1 + g], q, qinv);
+            else ct_butterfly_fp_nr(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wq[(1 << s) - 1 + g], q);
         }
     }
 }
@@ -498,11 +507,14 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_row_tail_sum(SumArgs a, NttT
     ulong2 acc[PAIRS];
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) acc[i] = ulong2{0, 0};
-    for (uint32_t c = 0; c < a.n_clients; ++c) {
-        const u64 *src = a.conv + (size_t)c * a.conv_cstride + ((size_t)poly * a.nl + sl) * n + tile_off;
-        u64 x[H], w[H - 1], wp[H - 1];
+    // software pipeline over clients: the H input words of client c+1 are requested while client c's tail streams
+    // (x[] is dead by then), so their latency is off the critical path
+    const u64 *src0 = a.conv + ((size_t)poly * a.nl + sl) * n + tile_off + (size_t)g * R + j;
+    u64 x[H];
 #pragma unroll
-        for (int k = 0; k < H; ++k) x[k] = src[(size_t)g * R + j + H * k];
+    for (int k = 0; k < H; ++k) x[k] = src0[H * k];
+    for (uint32_t c = 0; c < a.n_clients; ++c) {
+        u64 w[H - 1], wp[H - 1];
         __syncthreads();  // twiddles staged (first client) / previous client's copy-out finished reading LDS
         TA::fetch(twa, twa_sh, g, w, wp);
         radix_forward_any<LOG_H, FP>(x, w, wp, lc);
@@ -516,6 +528,11 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_row_tail_sum(SumArgs a, NttT
 #pragma unroll
         for (int k = 0; k < H; ++k)
             lds[TL::at(g, H * j + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
+        if (c + 1 < a.n_clients) {
+            const u64 *nxt = src0 + (size_t)(c + 1) * a.conv_cstride;
+#pragma unroll
+            for (int k = 0; k < H; ++k) x[k] = nxt[H * k];
+        }
         __syncthreads();
         const u64 *tq = a.til + (size_t)c * a.til_cstride + ((size_t)poly * a.ext + sl) * n + tile_off;
         const u64 *c0 = (poly & 1) == 0

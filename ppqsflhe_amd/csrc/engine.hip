@@ -408,6 +408,7 @@ __global__ void k_fma(Opnd x, Opnd y, Opnd z, Opnd w, const u64 *wc, int negate_
 // =====================================================================================
 
 static int fast_log_h(uint32_t log_r, uint32_t other_extent);
+static int fast_row(uint32_t log_r2, uint32_t rows);
 
 static dim3 ew_grid(uint32_t n, uint32_t slots, uint32_t items) {
     return dim3((n / 2 + EW_THREADS - 1) / EW_THREADS, slots, items);
@@ -432,7 +433,7 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
         if (std::atoi(e) == 1) { tabs_.log_r1 = ps_.log_n / 2; tabs_.log_r2 = ps_.log_n - tabs_.log_r1; }
     // fp64 limbs: only when BOTH passes run on the radix kernels (the generic LDS-stage kernels are integer-only)
     // and the modulus is below 1.25 * 2^50 (bounds in ntt_radix.hpp).  MKCKKS_NO_FP64=1 keeps everything integer.
-    const bool radix_both = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) && fast_log_h(tabs_.log_r2, 1u << tabs_.log_r1);
+    const bool radix_both = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) && fast_row(tabs_.log_r2, 1u << tabs_.log_r1);
     const char *nofp = std::getenv("MKCKKS_NO_FP64");
     const bool fp_ok = radix_both && !(nofp && std::atoi(nofp) == 1);
     tabs_.has_fp = 0;
@@ -652,6 +653,11 @@ static int fast_log_h(uint32_t log_r, uint32_t other_extent) {
     const uint32_t h = 1u << (log_r / 2);
     return (256u / h) <= other_extent ? (int)(log_r / 2) : 0;
 }
+// row pass only: 512-point rows take the three-round radix-8 kernel (code 9)
+static int fast_row(uint32_t log_r2, uint32_t rows) {
+    if (log_r2 == 9 && rows >= 4) return 9;
+    return fast_log_h(log_r2, rows);
+}
 
 // pack != 0 (inverse radix kernels only): results leave as packed 30-bit halves for k_conv_col
 // The integer and the fp64 instance of a pass touch disjoint limbs: when both have work they are launched on two
@@ -725,7 +731,13 @@ static void launch_row(const NttIo &io0, const NttTables &T, uint32_t n_polys, c
     io.nsel = (uint32_t)__builtin_popcountll(io.slot_mask);
     iof.nsel = (uint32_t)__builtin_popcountll(iof.slot_mask);
     const uint32_t items = n_polys * io.nsel, itemsf = n_polys * iof.nsel;
-    switch (fast_log_h(T.log_r2, r1)) {
+    switch (fast_row(T.log_r2, r1)) {
+        case 9:
+            if (tail.enabled) throw std::logic_error("fused tail needs the 256-point row kernel");
+            launch_two_classes(ln, items != 0, itemsf != 0,
+                [&](hipStream_t s) { k_ntt_row3<INV, false><<<dim3((r1 / 4) * items), NTT_THREADS, 0, s>>>(io, T); },
+                [&](hipStream_t s) { k_ntt_row3<INV, true><<<dim3((r1 / 4) * itemsf), NTT_THREADS, 0, s>>>(iof, T); });
+            break;
         case 4:
             launch_two_classes(ln, items != 0, itemsf != 0,
                 [&](hipStream_t s) { k_ntt_row_r<4, INV, false><<<dim3((r1 / 16) * items), NTT_THREADS, 0, s>>>(io, T, tail); },
@@ -1017,13 +1029,14 @@ void Engine::moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t o
                           size_t add_stride, uint32_t cnt, uint32_t nl, bool accumulate) {
     const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, D = ps_.D;
     const u64 *fold = folded_scale(nl), *pinv = p_inverse(nl);
-    const bool fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0 && row_tail_supported(tabs_);
+    const bool conv_fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0;  // conversion inside the column pass
+    const bool tail_fused = conv_fused && row_tail_supported(tabs_);               // tail inside the row pass
     NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
-    ntt_passes(s5, tabs_, cnt, true, fold, fold + D, lanes(), fused ? 1 : 0);
+    ntt_passes(s5, tabs_, cnt, true, fold, fold + D, lanes(), conv_fused ? 1 : 0);
     const DevConv &cv = moddown_conv(nl);
     ConvIo io{pc, conv, (size_t)K * n, (size_t)nl * n, cnt, 0, 0};
     EwGeom g{n, nl, ps_.L};
-    if (fused) {
+    if (tail_fused) {
         launch_conv_col(io, tabs_, cv, lanes());
         // row pass of the converted limbs with the (ctilde_Q - conv) * P^-1 (+ c0) tail in its copy-out
         NttIo row{conv, out, (size_t)nl * n, out_stride, 0, 0, 0, nl, nl};
@@ -1032,8 +1045,14 @@ void Engine::moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t o
         MK_HIP(hipGetLastError());
         return;
     }
-    launch_baseconv(pc, (size_t)K * n, conv, (size_t)nl * n, cv, d_limb_, n, cnt, 1, stream_);
-    ntt_launch(conv, cnt, nl, nl, false, nullptr, nullptr);
+    if (conv_fused) {  // e.g. N = 2^17: fused conversion + column pass, plain row pass, tail as its own kernel
+        launch_conv_col(io, tabs_, cv, lanes());
+        NttIo row{conv, conv, (size_t)nl * n, (size_t)nl * n, 0, 0, 0, nl, nl};
+        launch_row<false>(row, tabs_, cnt, TailArgs{}, lanes());
+    } else {
+        launch_baseconv(pc, (size_t)K * n, conv, (size_t)nl * n, cv, d_limb_, n, cnt, 1, stream_);
+        ntt_launch(conv, cnt, nl, nl, false, nullptr, nullptr);
+    }
     k_moddown_tail<<<ew_grid(n, nl, cnt), EW_THREADS, 0, stream_>>>(til, conv, out, g, d_limb_, ext, pinv, pinv + nl,
                                                                  add, add_stride, out_stride, accumulate ? 1 : 0);
     MK_HIP(hipGetLastError());

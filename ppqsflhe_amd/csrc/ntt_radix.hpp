@@ -560,4 +560,146 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_row_tail_sum(SumArgs a, NttT
     for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[threadIdx.x + i * NTT_THREADS] = acc[i];
 }
 
+// ---- 512-point rows (N = 2^17 = 256 x 512): three rounds of radix 8 ---------------------------------------
+// Position x = 64a + 8b + c of a row; a thread is (p, r) with p, r < 8 and holds 8 words per round:
+//   round A: (a,b,c) = (k,p,r)  stages 0-2  base_eff = base
+//   round B: (a,b,c) = (p,k,r)  stages 3-5  base_eff = 8 base + p
+//   round C: (a,b,c) = (p,r,k)  stages 6-8  base_eff = 64 base + 8p + r       (forward; the inverse runs C, B, A)
+// A workgroup owns 4 consecutive rows (2048 contiguous words); two LDS exchanges; layout x + x/8 per row (stride
+// 576) is conflict-free for all three access patterns.  Round A and B twiddles are shared by 64 resp. 8 threads and
+// go through LDS (contiguous runs over the tile), round C twiddles are per thread.
+struct Row3 {
+    static constexpr int H = 8, ROWS = 4, R = 512, RS = 576, WORDS = ROWS * RS;
+    static constexpr int TWA = ROWS * 7, TWB = ROWS * 8 * 7;  // per table
+    static MK_D int at(int g, int x) { return g * RS + x + (x >> 3); }
+};
+template <bool INV, bool FP>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T) {
+    using TL = Row3;
+    constexpr int H = 8, LOG_H = 3, R = TL::R, S = TL::ROWS;
+    __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
+    u64 *twa = lds + TL::WORDS, *twa_sh = twa + TL::TWA, *twb = twa_sh + TL::TWA, *twb_sh = twb + TL::TWB;
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
+    const uint32_t tiles = r1 / S, groups = tiles * io.nsel, n_polys = gridDim.x / groups;
+    uint32_t grp, poly;
+    if (groups % 8 == 0) {
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / n_polys) * 8 + xcd;
+        poly = qidx % n_polys;
+    } else {
+        grp = blockIdx.x / n_polys;
+        poly = blockIdx.x % n_polys;
+    }
+    const uint32_t sl = nth_set_bit(io.slot_mask, grp / tiles);
+    if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;
+    const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
+    const LimbConst lc = T.limb[id];
+    if ((lc.fp != 0) != FP) return;
+    const uint32_t row0 = (grp % tiles) * S;
+    const int g = threadIdx.x / 64, t = threadIdx.x % 64, p = t / 8, r = t % 8;
+    const u64 *src = io.in + (size_t)poly * io.in_stride + (size_t)(io.in_slot0 + sl) * n + (size_t)row0 * R;
+    u64 *dst = io.out + (size_t)poly * io.out_stride + (size_t)(io.out_slot0 + sl) * n + (size_t)row0 * R;
+    const u64 *tw = (INV ? T.itw : T.tw) + (size_t)id * n;
+    const u64 *tw_sh = (INV ? T.itw_sh : T.tw_sh) + (size_t)id * n;
+    const uint32_t base = r1 + row0 + g;
+    // stage the shared twiddles: stage-s entries of rounds A / B are contiguous runs over the 4 rows
+    for (int e = threadIdx.x; e < TL::TWA; e += NTT_THREADS) {
+        const int s = 31 - __clz(e / S + 1), off = e - S * ((1 << s) - 1);
+        const uint32_t idx = ((r1 + row0) << s) + (uint32_t)off;
+        twa[e] = tw[idx];
+        twa_sh[e] = tw_sh[idx];
+    }
+    for (int e = threadIdx.x; e < TL::TWB; e += NTT_THREADS) {
+        const int s = 31 - __clz(e / (S * 8) + 1), off = e - S * 8 * ((1 << s) - 1);
+        const uint32_t idx = (((r1 + row0) * 8) << s) + (uint32_t)off;
+        twb[e] = tw[idx];
+        twb_sh[e] = tw_sh[idx];
+    }
+    u64 x[H], w[H - 1], wp[H - 1];
+    auto fetch_a = [&]() {
+#pragma unroll
+        for (int s = 0; s < LOG_H; ++s)
+#pragma unroll
+            for (int gg = 0; gg < (1 << s); ++gg) {
+                const int e = S * ((1 << s) - 1) + (g << s) + gg;
+                w[(1 << s) - 1 + gg] = twa[e];
+                wp[(1 << s) - 1 + gg] = twa_sh[e];
+            }
+    };
+    auto fetch_b = [&]() {
+#pragma unroll
+        for (int s = 0; s < LOG_H; ++s)
+#pragma unroll
+            for (int gg = 0; gg < (1 << s); ++gg) {
+                const int e = S * 8 * ((1 << s) - 1) + ((g * 8 + p) << s) + gg;
+                w[(1 << s) - 1 + gg] = twb[e];
+                wp[(1 << s) - 1 + gg] = twb_sh[e];
+            }
+    };
+    if (!INV) {
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = src[(size_t)g * R + t + 64 * k];  // doubles from the column pass on an fp limb
+        __syncthreads();
+        fetch_a();
+        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(g, t + 64 * k)] = x[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, 64 * p + 8 * k + r)];
+        fetch_b();
+        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(g, 64 * p + 8 * k + r)] = x[k];  // own words
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, 64 * p + 8 * r + k)];
+        load_round_twiddles<LOG_H>(tw, tw_sh, base * 64 + 8 * p + r, w, wp);
+        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+#pragma unroll
+        for (int k = 0; k < H; ++k)
+            lds[TL::at(g, 64 * p + 8 * r + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
+        __syncthreads();
+        for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
+            const int gg = (2 * e) / R, xx = (2 * e) % R;
+            ulong2 v;
+            v.x = lds[TL::at(gg, xx)];
+            v.y = lds[TL::at(gg, xx + 1)];
+            reinterpret_cast<ulong2 *>(dst)[e] = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
+            const int gg = (2 * e) / R, xx = (2 * e) % R;
+            const ulong2 v = reinterpret_cast<const ulong2 *>(src)[e];
+            lds[TL::at(gg, xx)] = v.x;
+            lds[TL::at(gg, xx + 1)] = v.y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, 64 * p + 8 * r + k)];
+        if (FP) {
+#pragma unroll
+            for (int k = 0; k < H; ++k) x[k] = dbits((double)x[k]);
+        }
+        load_round_twiddles<LOG_H>(tw, tw_sh, base * 64 + 8 * p + r, w, wp);
+        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(g, 64 * p + 8 * r + k)] = x[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, 64 * p + 8 * k + r)];
+        fetch_b();
+        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(g, 64 * p + 8 * k + r)] = x[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, t + 64 * k)];
+        fetch_a();
+        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
+#pragma unroll
+        for (int k = 0; k < H; ++k) dst[(size_t)g * R + t + 64 * k] = x[k];  // lazy [0,2q) / doubles: the column pass scales
+    }
+}
+
 }  // namespace mk

@@ -126,7 +126,8 @@ private:
     u64 *d_tw_ = nullptr, *d_tw_sh_ = nullptr, *d_itw_ = nullptr, *d_itw_sh_ = nullptr;
     std::vector<uint8_t> fp_of_;  // per limb id: 1 = fp64 kernel instance
     hipStream_t side_stream_ = nullptr;  // second lane for the fp64 instances of a pass
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    hipStream_t sum_stream_ = nullptr;   // fused sum kernels of finished client groups (reencrypt_sum)
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_a_ = nullptr, ev_b_ = nullptr;
     bool two_lanes_ = false;
     uint32_t *d_rot_ = nullptr;
     void *d_ksi_ = nullptr;

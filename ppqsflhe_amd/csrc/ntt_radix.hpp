@@ -475,6 +475,7 @@ struct SumArgs {
     uint32_t n_clients, nl, ext, n_polys;
     unsigned long long slot_mask;
     uint32_t nsel;
+    uint32_t init_from_out;  // continue a running sum: the accumulators start from `out` instead of zero
 };
 template <int LOG_H, bool FP>
 __global__ __launch_bounds__(NTT_THREADS, 4) void k_row_tail_sum(SumArgs a, NttTables T) {
@@ -504,9 +505,11 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_row_tail_sum(SumArgs a, NttT
     const u64 pi = a.pinv[sl], pi_sh = a.pinv_sh[sl];
     const size_t tile_off = (size_t)row0 * R;
     TA::stage(twa, twa_sh, tw, tw_sh, r1 + row0);  // round-A twiddles are the same for every client
+    u64 *dst = a.out + ((size_t)poly * a.nl + sl) * n + tile_off;
     ulong2 acc[PAIRS];
 #pragma unroll
-    for (int i = 0; i < PAIRS; ++i) acc[i] = ulong2{0, 0};
+    for (int i = 0; i < PAIRS; ++i)
+        acc[i] = a.init_from_out ? reinterpret_cast<const ulong2 *>(dst)[threadIdx.x + i * NTT_THREADS] : ulong2{0, 0};
     // software pipeline over clients: the H input words of client c+1 are requested while client c's tail streams
     // (x[] is dead by then), so their latency is off the critical path
     const u64 *src0 = a.conv + ((size_t)poly * a.nl + sl) * n + tile_off + (size_t)g * R + j;
@@ -555,7 +558,6 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_row_tail_sum(SumArgs a, NttT
             acc[i].y = add_mod(acc[i].y, v.y, lc.q);
         }
     }
-    u64 *dst = a.out + ((size_t)poly * a.nl + sl) * n + tile_off;
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[threadIdx.x + i * NTT_THREADS] = acc[i];
 }

@@ -1135,8 +1135,18 @@ static void launch_row_tail_sum(SumArgs a, const NttTables &T, uint32_t L, hipSt
     ai.nsel = (uint32_t)__builtin_popcountll(ai.slot_mask);
     af.nsel = (uint32_t)__builtin_popcountll(af.slot_mask);
     (void)L;
-    if (ai.nsel) k_row_tail_sum<LOG_H, false><<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s>>>(ai, T);
-    if (af.nsel) k_row_tail_sum<LOG_H, true><<<dim3(tiles * af.nsel * a.n_polys), NTT_THREADS, 0, s>>>(af, T);
+    static const int waves = [] { const char *e = std::getenv("MKCKKS_SUM_WAVES"); return e ? std::atoi(e) : 2; }();  // 2: no spills (212 VGPRs); measured equal to 3, faster than 4
+    const dim3 gi(tiles * ai.nsel * a.n_polys), gf(tiles * af.nsel * a.n_polys);
+    if (waves == 2) {
+        if (ai.nsel) k_row_tail_sum<LOG_H, false, 2><<<gi, NTT_THREADS, 0, s>>>(ai, T);
+        if (af.nsel) k_row_tail_sum<LOG_H, true, 2><<<gf, NTT_THREADS, 0, s>>>(af, T);
+    } else if (waves == 4) {
+        if (ai.nsel) k_row_tail_sum<LOG_H, false, 4><<<gi, NTT_THREADS, 0, s>>>(ai, T);
+        if (af.nsel) k_row_tail_sum<LOG_H, true, 4><<<gf, NTT_THREADS, 0, s>>>(af, T);
+    } else {
+        if (ai.nsel) k_row_tail_sum<LOG_H, false, 3><<<gi, NTT_THREADS, 0, s>>>(ai, T);
+        if (af.nsel) k_row_tail_sum<LOG_H, true, 3><<<gf, NTT_THREADS, 0, s>>>(af, T);
+    }
 }
 
 // sum over clients of ReEncrypt(ct_c[b], evk_c): everything up to the column pass of ModDown runs per client (two

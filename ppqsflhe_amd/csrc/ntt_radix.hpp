@@ -477,8 +477,8 @@ struct SumArgs {
     uint32_t nsel;
     uint32_t init_from_out;  // continue a running sum: the accumulators start from `out` instead of zero
 };
-template <int LOG_H, bool FP>
-__global__ __launch_bounds__(NTT_THREADS, 4) void k_row_tail_sum(SumArgs a, NttTables T) {
+template <int LOG_H, bool FP, int WAVES>
+__global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, NttTables T) {
     using TL = RowTile<LOG_H>;
     using TA = RowTwA<LOG_H>;
     constexpr int H = TL::H, S = TL::S, R = TL::R, PAIRS = S * R / 2 / NTT_THREADS;

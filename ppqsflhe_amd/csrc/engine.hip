@@ -726,7 +726,9 @@ static void launch_col(const NttIo &io0, const NttTables &T, uint32_t n_polys, c
     }
 }
 
-static bool row_tail_supported(const NttTables &T) { return fast_log_h(T.log_r2, 1u << T.log_r1) != 0; }
+static bool row_tail_supported(const NttTables &T) { return fast_row(T.log_r2, 1u << T.log_r1) != 0; }
+// the fused n-client sum kernel exists for the two-round row kernels only
+static bool row_sum_supported(const NttTables &T) { return fast_log_h(T.log_r2, 1u << T.log_r1) != 0; }
 
 template <bool INV>
 static void launch_row(const NttIo &io0, const NttTables &T, uint32_t n_polys, const TailArgs &tail, const Lanes &ln) {
@@ -739,10 +741,9 @@ static void launch_row(const NttIo &io0, const NttTables &T, uint32_t n_polys, c
     const uint32_t items = n_polys * io.nsel, itemsf = n_polys * iof.nsel;
     switch (fast_row(T.log_r2, r1)) {
         case 9:
-            if (tail.enabled) throw std::logic_error("fused tail needs the 256-point row kernel");
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { k_ntt_row3<INV, false><<<dim3((r1 / 4) * items), NTT_THREADS, 0, s>>>(io, T); },
-                [&](hipStream_t s) { k_ntt_row3<INV, true><<<dim3((r1 / 4) * itemsf), NTT_THREADS, 0, s>>>(iof, T); });
+                [&](hipStream_t s) { k_ntt_row3<INV, false><<<dim3((r1 / 4) * items), NTT_THREADS, 0, s>>>(io, T, tail); },
+                [&](hipStream_t s) { k_ntt_row3<INV, true><<<dim3((r1 / 4) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
             break;
         case 4:
             launch_two_classes(ln, items != 0, itemsf != 0,
@@ -1157,8 +1158,8 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
     if (!n_clients || !n_ct) return;
     const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, nparts = ps_.num_parts(nl), D = ps_.D;
     const size_t ct_words = (size_t)2 * nl * n, evk_words = (size_t)ps_.beta * 2 * D * n;
-    const bool fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0 && row_tail_supported(tabs_);
-    if (!fused) {  // ring sizes without radix kernels: plain loop with the accumulating tail
+    const bool fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0 && row_sum_supported(tabs_);
+    if (!fused) {  // ring sizes without the fused sum kernel: plain loop with the accumulating tail
         for (uint32_t c = 0; c < n_clients; ++c)
             reencrypt(cts + (size_t)c * n_ct * ct_words, evks + (size_t)c * evk_words, out, n_ct, nl, c != 0);
         return;

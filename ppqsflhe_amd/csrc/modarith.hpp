@@ -175,6 +175,29 @@ MK_HD u64 reduce_cols_lazy(const Cols &c, const LimbConst &L) {  // result in [0
 MK_HD u64 reduce_cols(const Cols &c, const LimbConst &L) {
     return csub(csub(reduce_cols_lazy(c, L), L.q2), L.q);
 }
+// 5..8 terms: the middle column is kept as two sums (each <= 8 * 2^60 fits), and the total (< 2^123) goes through
+// the folding reduction.
+struct Cols4 {
+    u64 c0, c1a, c1b, c2;
+};
+MK_HD void mac_cols4(Cols4 &c, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {
+    c.c0 = (u64)a0 * b0 + c.c0;
+    c.c1a = (u64)a0 * b1 + c.c1a;
+    c.c1b = (u64)a1 * b0 + c.c1b;
+    c.c2 = (u64)a1 * b1 + c.c2;
+}
+MK_HD void add128(u64 &hi, u64 &lo, u64 xhi, u64 xlo) {
+    lo += xlo;
+    hi += xhi + (lo < xlo ? 1 : 0);
+}
+MK_HD u64 reduce_cols4(const Cols4 &c, const LimbConst &L) {  // canonical
+    u64 hi = 0, lo = c.c0;
+    add128(hi, lo, c.c1a >> 34, c.c1a << 30);
+    add128(hi, lo, c.c1b >> 34, c.c1b << 30);
+    add128(hi, lo, c.c2 >> 4, c.c2 << 60);
+    return reduce_wide(hi, lo, L);
+}
+
 // a 60-bit word stored as its two 30-bit halves in the two 32-bit halves of a u64 (what split30 would produce)
 MK_HD u64 pack30(u64 v) { return (v & 0x3FFFFFFFull) | ((v >> 30) << 32); }
 MK_HD u64 unpack30(u64 p) { return (p & 0xFFFFFFFFull) | ((p >> 32) << 30); }

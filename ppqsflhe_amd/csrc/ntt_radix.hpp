@@ -312,16 +312,19 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
             x[k] = reduce_cols_lazy(acc, lc);  // < 4q: the first butterfly stage accepts < 8q
         }
     } else {
-        u64 hat[N_IN];
+        // 5..8 sources (e.g. alpha = K = 7 at L = 20): same 30-bit columns with the middle one split in two
+        uint32_t h0[N_IN], h1[N_IN];
 #pragma unroll
-        for (int i = 0; i < N_IN; ++i) hat[i] = cv.hat[i * cv.n_out + jt];
+        for (int i = 0; i < N_IN; ++i) split30(cv.hat[i * cv.n_out + jt], h0[i], h1[i]);
 #pragma unroll
         for (int k = 0; k < H; ++k) {
-            u64 hi = 0, lo = 0;
+            Cols4 acc{0, 0, 0, 0};
 #pragma unroll
-            for (int i = 0; i < N_IN; ++i)
-                mac128(hi, lo, unpack30(src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2]), hat[i]);
-            x[k] = reduce_wide(hi, lo, lc);
+            for (int i = 0; i < N_IN; ++i) {
+                const u64 p = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2];
+                mac_cols4(acc, (uint32_t)p, (uint32_t)(p >> 32), h0[i], h1[i]);
+            }
+            x[k] = reduce_cols4(acc, lc);
         }
     }
     if (FP) {  // < 4q < 2^53: exact in a double; bring into the fp rounds' range
@@ -576,7 +579,7 @@ struct Row3 {
     static MK_D int at(int g, int x) { return g * RS + x + (x >> 3); }
 };
 template <bool INV, bool FP>
-__global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T) {
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T, TailArgs tail) {
     using TL = Row3;
     constexpr int H = 8, LOG_H = 3, R = TL::R, S = TL::ROWS;
     __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
@@ -662,12 +665,38 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T)
         for (int k = 0; k < H; ++k)
             lds[TL::at(g, 64 * p + 8 * r + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
         __syncthreads();
-        for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
-            const int gg = (2 * e) / R, xx = (2 * e) % R;
-            ulong2 v;
-            v.x = lds[TL::at(gg, xx)];
-            v.y = lds[TL::at(gg, xx + 1)];
-            reinterpret_cast<ulong2 *>(dst)[e] = v;
+        if (!tail.enabled) {
+            for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
+                const int gg = (2 * e) / R, xx = (2 * e) % R;
+                ulong2 v;
+                v.x = lds[TL::at(gg, xx)];
+                v.y = lds[TL::at(gg, xx + 1)];
+                reinterpret_cast<ulong2 *>(dst)[e] = v;
+            }
+        } else {  // ApproxModDown tail in the copy-out (same as k_ntt_row_r)
+            const u64 pi = tail.pinv[sl], pi_sh = tail.pinv_sh[sl];
+            const u64 *tq = tail.til + ((size_t)poly * tail.ext + sl) * n + (size_t)row0 * R;
+            const u64 *c0 = (tail.add && (poly & 1) == 0)
+                                ? tail.add + (size_t)(poly >> 1) * tail.add_stride + (size_t)sl * n + (size_t)row0 * R
+                                : nullptr;
+            for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
+                const int gg = (2 * e) / R, xx = (2 * e) % R;
+                const ulong2 tt = reinterpret_cast<const ulong2 *>(tq)[e];
+                ulong2 v;
+                v.x = shoup_mul(sub_mod(tt.x, lds[TL::at(gg, xx)], lc.q), pi, pi_sh, lc.q);
+                v.y = shoup_mul(sub_mod(tt.y, lds[TL::at(gg, xx + 1)], lc.q), pi, pi_sh, lc.q);
+                if (c0) {
+                    const ulong2 z = reinterpret_cast<const ulong2 *>(c0)[e];
+                    v.x = add_mod(v.x, z.x, lc.q);
+                    v.y = add_mod(v.y, z.y, lc.q);
+                }
+                if (tail.accumulate) {
+                    const ulong2 z = reinterpret_cast<const ulong2 *>(dst)[e];
+                    v.x = add_mod(v.x, z.x, lc.q);
+                    v.y = add_mod(v.y, z.y, lc.q);
+                }
+                reinterpret_cast<ulong2 *>(dst)[e] = v;
+            }
         }
     } else {
         for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {

@@ -17,8 +17,9 @@
 //   The inverse (Gentleman-Sande) runs the same two passes in the opposite order with
 //   the inverse table, then scales by N^-1 (optionally times a folded per-limb constant).
 //
-//   Butterflies are Harvey lazy: forward keeps values in [0,4q), inverse in [0,2q);
-//   only the last pass reduces to the canonical [0,q).
+//   Butterflies are Harvey lazy: forward keeps values below 8q (4q in these generic kernels), inverse below 2q;
+//   only the last pass reduces to the canonical [0,q).  The generic LDS-stage kernels in this file are the fallback
+//   for ring sizes the register kernels of ntt_radix.hpp do not cover (odd log N).
 #pragma once
 #include "modarith.hpp"
 

@@ -10,6 +10,12 @@
 //     round B: thread j holds x[H j + k], k < H      stages log H..2log H-1 base_eff = base*H + j
 //   inverse (Gentleman-Sande) runs round B then round A with the stages reversed.
 //   Twiddle of in-register stage s, group g (g < 2^s): table[(base_eff << s) + g].
+//
+// Every kernel exists in two arithmetic instances (template parameter FP): integer (Shoup/Harvey lazy butterflies on
+// v_mad_u64_u32) for the 60-bit limbs and fp64 (exact FMA products, see modarith.hpp) for limbs below 1.25 * 2^50;
+// the host launches each instance over the limbs of its class.  512-point rows (N = 2^17) use three rounds of
+// radix 8 (k_ntt_row3).  k_conv_col fuses the approximate base conversion into the forward column pass,
+// k_row_tail_sum the ModDown tail and the sum over clients into the forward row pass.
 #pragma once
 #include "modarith.hpp"
 #include "ntt_kernels.hpp"

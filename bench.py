@@ -77,6 +77,33 @@ def cpu_baseline(args, log):
                       f"dnum={args.dnum}; oracle/liboracle.so (OpenMP over limbs), {dt:.1f}s"}
 
 
+def verify_exchange(torch, dist, ctx, pipe, agg, out, ct_in, evk, C, B, Bs, L, world, rank, inv_n, log):
+    """Size-independent check of the N>1 exchange: the collective's unreduced integer sum + reduce_mod + rescale must
+    equal eval_sum (modular) over the all-gathered per-rank aggregates + rescale, bit for bit."""
+    torch.cuda.synchronize()
+    last = (pipe["k"] - 1) & 1 if pipe is not None else 0
+    got = (pipe["out"][last] if pipe is not None else out).clone()
+    ctx.reencrypt_sum(ct_in, evk, agg, C, B, L)
+    torch.cuda.synchronize()
+    parts = torch.empty((world,) + tuple(agg.shape), dtype=agg.dtype, device=agg.device)
+    if dist.get_backend() == "gloo":  # gloo moves GPU tensors only for broadcast / all_reduce
+        parts.zero_()
+        parts[rank].copy_(agg)
+        dist.all_reduce(parts, op=dist.ReduceOp.SUM)
+    else:
+        dist.all_gather_into_tensor(parts, agg)
+    total = torch.empty_like(agg)
+    ctx.eval_sum(parts, total, world, B, L)
+    want = torch.empty_like(got)
+    ctx.rescale_mult_const(total[rank * Bs:(rank + 1) * Bs].contiguous(), want, Bs, L, inv_n)
+    torch.cuda.synchronize()
+    ok = torch.tensor([int(torch.equal(got, want))], device=agg.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok) != 1:
+        raise SystemExit("[bench] --verify FAILED: exchange result differs from the modular sum")
+    log("[bench] --verify ok: reduce-scatter + reduce_mod + rescale == modular sum of the per-rank aggregates")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +117,9 @@ def main():
     ap.add_argument("--cts", type=int, default=16, help="ciphertexts per client (multiple of --gpus)")
     ap.add_argument("--cpu-sample", type=int, default=384, help="ciphertexts in the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="N>1 only, after the timed region: check the integer reduce-scatter + reduce_mod + rescale "
+                         "result against the modular sum of the gathered per-rank aggregates")
     ap.add_argument("--mode", choices=["sum", "accumulate"], default="sum",
                     help="sum: one reencrypt_sum_batch call over all clients (last ModDown pass + aggregation fused); "
                          "accumulate: per-client reencrypt_accumulate_batch calls spread over --streams")
@@ -114,10 +144,17 @@ def main():
         if rank == 0:
             print(msg, file=sys.stderr, flush=True)
 
+    # rehearsal knobs for a one-GPU box: every rank on device 0, collective carried by gloo
+    backend = os.environ.get("MKCKKS_BENCH_BACKEND", "nccl")
+    if os.environ.get("MKCKKS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     if args.cts % world:
         raise SystemExit("--cts must be a multiple of --gpus")
 
@@ -157,7 +194,36 @@ def main():
     inv_n = 1.0 / (C * world)
     lanes = [(None, ctx)] + side
 
+    # N>1: the exchange step of batch k (reduce-scatter over xGMI, reduce_mod, rescale of this rank's shard) runs on
+    # its own stream with its own context while the main stream already key-switches batch k+1; partial sums,
+    # shards and outputs are double-buffered, an event per buffer keeps batch k+2 off a buffer still in flight
+    pipe = None
+    if world > 1 and args.mode == "sum" and os.environ.get("MKCKKS_BENCH_SERIAL_EXCHANGE") != "1":
+        comm = torch.cuda.Stream(device=dev)
+        cx_tail = Context(args.log_n, args.depth, args.scaling_bits, 60, dnum=args.dnum, device=local_rank)
+        cx_tail.set_stream(comm.cuda_stream)
+        pipe = {"comm": comm, "ctx": cx_tail, "k": 0,
+                "agg": [agg, torch.empty_like(agg)], "shard": [shard, torch.empty_like(shard)],
+                "out": [out, torch.empty_like(out)], "free": [None, None]}
+
+    def step_sum_pipelined():
+        b = pipe["k"] & 1
+        pipe["k"] += 1
+        main = torch.cuda.current_stream()
+        if pipe["free"][b] is not None:
+            main.wait_event(pipe["free"][b])
+        ctx.reencrypt_sum(ct_in, evk, pipe["agg"][b], C, B, L)
+        ready = main.record_event()
+        with torch.cuda.stream(pipe["comm"]):
+            pipe["comm"].wait_event(ready)
+            reduce_partial_sums(pipe["agg"][b], pipe["shard"][b])
+            pipe["ctx"].reduce_mod(pipe["shard"][b], Bs, L, world)
+            pipe["ctx"].rescale_mult_const(pipe["shard"][b], pipe["out"][b], Bs, L, inv_n)
+            pipe["free"][b] = pipe["comm"].record_event()
+
     def step_sum():
+        if pipe is not None:
+            return step_sum_pipelined()
         ctx.reencrypt_sum(ct_in, evk, agg, C, B, L)
         if world > 1:
             reduce_partial_sums(agg, shard)
@@ -209,6 +275,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, gpu_ms = float(t[0]), float(t[1])
 
+    if world > 1:
+        gpu_ms = dt * 1e3  # the exchange runs on a second stream: the main-stream events miss it, wall time does not
+        if args.verify:
+            verify_exchange(torch, dist, ctx, pipe, agg, out, ct_in, evk, C, B, Bs, L, world, rank, inv_n, log)
+
     units_per_step = C * B * world
     value = units_per_step * args.steps / dt
     bytes_unit = algorithmic_bytes_per_unit(N, L, K, beta, C * world)
@@ -217,7 +288,7 @@ def main():
     achieved = bytes_unit * C * B / step_s_gpu / 1e9
     traffic = None
     prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(prof):
+    if os.path.exists(prof) and world == 1:  # the PMC passes were taken on the single-GPU step
         try:
             rec = json.load(open(prof))
             key = f"logn{args.log_n}_L{L}_dnum{args.dnum}_C{C}_B{B}"
@@ -232,7 +303,7 @@ def main():
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"C3+C4: {C} clients x {B} ct per GPU, N=2^{args.log_n}, L={L}, K={K}, dnum={args.dnum}: "
                                + ("reencrypt_sum_batch (hybrid key-switch PRE of every client, last ModDown pass fused with the sum) -> " if args.mode == "sum" else "reencrypt_accumulate_batch (hybrid key-switch PRE folded into the aggregate) -> ")
-                               + ("RCCL reduce_scatter(u64 sum)+reduce_mod -> " if world > 1 else "")
+                               + ("RCCL reduce_scatter(u64 sum)+reduce_mod" + (" (overlapped with the next batch's key switch)" if pipe else "") + " -> " if world > 1 else "")
                                + "rescale_mult_const(1/n)",
                    "ring_dim": N, "limbs": L, "special_limbs": K, "dnum": args.dnum, "clients_per_gpu": C,
                    "ct_per_client": B, "units_per_step": units_per_step, "sharding": f"clients x{world}"},
@@ -253,6 +324,8 @@ def main():
     ctx.close()
     for _, c2 in side:
         c2.close()
+    if pipe is not None:
+        pipe["ctx"].close()
     if world > 1:
         dist.destroy_process_group()
 

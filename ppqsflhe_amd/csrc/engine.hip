@@ -1138,7 +1138,12 @@ static void launch_row_tail_sum(SumArgs a, const NttTables &T, uint32_t L, hipSt
     (void)L;
     static const int waves = [] { const char *e = std::getenv("MKCKKS_SUM_WAVES"); return e ? std::atoi(e) : 2; }();  // 2: no spills (212 VGPRs); measured equal to 3, faster than 4
     const dim3 gi(tiles * ai.nsel * a.n_polys), gf(tiles * af.nsel * a.n_polys);
-    if (waves == 2) {
+    // two clients per workgroup iteration (shared twiddle fetches, two dependency chains): the default
+    static const bool pair = [] { const char *e = std::getenv("MKCKKS_SUM_PAIR"); return !e || std::atoi(e) != 0; }();
+    if (pair && LOG_H == 4) {
+        if (ai.nsel) k_row_tail_sum2<LOG_H, false><<<gi, NTT_THREADS, 0, s>>>(ai, T);
+        if (af.nsel) k_row_tail_sum2<LOG_H, true><<<gf, NTT_THREADS, 0, s>>>(af, T);
+    } else if (waves == 2) {
         if (ai.nsel) k_row_tail_sum<LOG_H, false, 2><<<gi, NTT_THREADS, 0, s>>>(ai, T);
         if (af.nsel) k_row_tail_sum<LOG_H, true, 2><<<gf, NTT_THREADS, 0, s>>>(af, T);
     } else if (waves == 4) {

@@ -571,6 +571,134 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, 
     for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[threadIdx.x + i * NTT_THREADS] = acc[i];
 }
 
+// Same pass with TWO clients in flight per workgroup iteration: both clients' tiles go through the rounds together,
+// so every twiddle fetched (LDS broadcast in round A, per-thread global loads in round B) feeds two butterflies and
+// the two independent dependency chains cover each other's LDS / memory latency at 2 waves per SIMD.  An odd client
+// count runs its last iteration with the second slot masked (its loads alias the first slot's client).
+template <int LOG_H, bool FP>
+__global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, NttTables T) {
+    using TL = RowTile<LOG_H>;
+    using TA = RowTwA<LOG_H>;
+    constexpr int H = TL::H, S = TL::S, R = TL::R, PAIRS = S * R / 2 / NTT_THREADS;
+    __shared__ u64 lds[2 * TL::WORDS + 2 * TA::WORDS];
+    u64 *ldsb = lds + TL::WORDS, *twa = lds + 2 * TL::WORDS, *twa_sh = twa + TA::WORDS;
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
+    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
+    uint32_t grp, poly;
+    if (groups % 8 == 0) {
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / a.n_polys) * 8 + xcd;
+        poly = qidx % a.n_polys;
+    } else {
+        grp = blockIdx.x / a.n_polys;
+        poly = blockIdx.x % a.n_polys;
+    }
+    const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);  // Q limb: slot == limb id
+    const LimbConst lc = T.limb[sl];
+    if ((lc.fp != 0) != FP) return;
+    const uint32_t row0 = (grp % tiles) * S;
+    const int g = threadIdx.x / H, j = threadIdx.x % H;
+    const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
+    const uint32_t base = r1 + row0 + g;
+    const u64 pi = a.pinv[sl], pi_sh = a.pinv_sh[sl];
+    const size_t tile_off = (size_t)row0 * R;
+    TA::stage(twa, twa_sh, tw, tw_sh, r1 + row0);
+    u64 *dst = a.out + ((size_t)poly * a.nl + sl) * n + tile_off;
+    ulong2 acc[PAIRS];
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i)
+        acc[i] = a.init_from_out ? reinterpret_cast<const ulong2 *>(dst)[threadIdx.x + i * NTT_THREADS] : ulong2{0, 0};
+    const u64 *src0 = a.conv + ((size_t)poly * a.nl + sl) * n + tile_off + (size_t)g * R + j;
+    const size_t til_off = ((size_t)poly * a.ext + sl) * n + tile_off;
+    const size_t ct_off = (size_t)(poly >> 1) * a.ct_stride + (size_t)sl * n + tile_off;
+    const bool with_c0 = (poly & 1) == 0;
+    u64 xa[H], xb[H];
+    {
+        const u64 *pb = src0 + (size_t)(a.n_clients > 1 ? 1 : 0) * a.conv_cstride;
+#pragma unroll
+        for (int k = 0; k < H; ++k) xa[k] = src0[H * k];
+#pragma unroll
+        for (int k = 0; k < H; ++k) xb[k] = pb[H * k];
+    }
+    for (uint32_t c = 0; c < a.n_clients; c += 2) {
+        const bool has_b = c + 1 < a.n_clients;  // workgroup-uniform
+        const uint32_t cb = has_b ? c + 1 : c;
+        {
+            u64 w[H - 1], wp[H - 1];
+            __syncthreads();  // twiddles staged (first pair) / previous pair's tail finished reading LDS
+            TA::fetch(twa, twa_sh, g, w, wp);
+            radix_forward_any<LOG_H, FP>(xa, w, wp, lc);
+            radix_forward_any<LOG_H, FP>(xb, w, wp, lc);
+        }
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            lds[TL::at(g, j + H * k)] = xa[k];
+            ldsb[TL::at(g, j + H * k)] = xb[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            xa[k] = lds[TL::at(g, H * j + k)];
+            xb[k] = ldsb[TL::at(g, H * j + k)];
+        }
+        {
+            u64 w[H - 1], wp[H - 1];
+            load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);
+            radix_forward_any<LOG_H, FP>(xa, w, wp, lc);
+            radix_forward_any<LOG_H, FP>(xb, w, wp, lc);
+        }
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            lds[TL::at(g, H * j + k)] = FP ? fp_to_canonical(bitsd(xa[k]), lc.qd, lc.qinv) : canon8(xa[k], lc.q, lc.q2);
+            ldsb[TL::at(g, H * j + k)] = FP ? fp_to_canonical(bitsd(xb[k]), lc.qd, lc.qinv) : canon8(xb[k], lc.q, lc.q2);
+        }
+        if (c + 2 < a.n_clients) {  // next pair's inputs are requested while this pair's tail streams
+            const u64 *na = src0 + (size_t)(c + 2) * a.conv_cstride;
+            const u64 *nb = src0 + (size_t)(c + 3 < a.n_clients ? c + 3 : c + 2) * a.conv_cstride;
+#pragma unroll
+            for (int k = 0; k < H; ++k) xa[k] = na[H * k];
+#pragma unroll
+            for (int k = 0; k < H; ++k) xb[k] = nb[H * k];
+        }
+        __syncthreads();
+        const u64 *tqa = a.til + (size_t)c * a.til_cstride + til_off;
+        const u64 *tqb = a.til + (size_t)cb * a.til_cstride + til_off;
+        const u64 *c0a = a.cts + (size_t)c * a.ct_cstride + ct_off;
+        const u64 *c0b = a.cts + (size_t)cb * a.ct_cstride + ct_off;
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = threadIdx.x + i * NTT_THREADS;
+            const int gg = (2 * e) / R, xx = (2 * e) % R;
+            const ulong2 ta = reinterpret_cast<const ulong2 *>(tqa)[e];
+            const ulong2 tb = reinterpret_cast<const ulong2 *>(tqb)[e];
+            ulong2 va, vb;
+            va.x = shoup_mul(sub_mod(ta.x, lds[TL::at(gg, xx)], lc.q), pi, pi_sh, lc.q);
+            va.y = shoup_mul(sub_mod(ta.y, lds[TL::at(gg, xx + 1)], lc.q), pi, pi_sh, lc.q);
+            vb.x = shoup_mul(sub_mod(tb.x, ldsb[TL::at(gg, xx)], lc.q), pi, pi_sh, lc.q);
+            vb.y = shoup_mul(sub_mod(tb.y, ldsb[TL::at(gg, xx + 1)], lc.q), pi, pi_sh, lc.q);
+            if (with_c0) {
+                const ulong2 za = reinterpret_cast<const ulong2 *>(c0a)[e];
+                const ulong2 zb = reinterpret_cast<const ulong2 *>(c0b)[e];
+                va.x = add_mod(va.x, za.x, lc.q);
+                va.y = add_mod(va.y, za.y, lc.q);
+                vb.x = add_mod(vb.x, zb.x, lc.q);
+                vb.y = add_mod(vb.y, zb.y, lc.q);
+            }
+            acc[i].x = add_mod(acc[i].x, va.x, lc.q);
+            acc[i].y = add_mod(acc[i].y, va.y, lc.q);
+            if (has_b) {
+                acc[i].x = add_mod(acc[i].x, vb.x, lc.q);
+                acc[i].y = add_mod(acc[i].y, vb.y, lc.q);
+            }
+            // keep the loads of the second half of the tile behind the first half's arithmetic: hoisting all
+            // 4*PAIRS 16-byte loads at once overflows the register file (the next pair's inputs are in flight too)
+            if (i == PAIRS / 2 - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[threadIdx.x + i * NTT_THREADS] = acc[i];
+}
+
 // ---- 512-point rows (N = 2^17 = 256 x 512): three rounds of radix 8 ---------------------------------------
 // Position x = 64a + 8b + c of a row; a thread is (p, r) with p, r < 8 and holds 8 words per round:
 //   round A: (a,b,c) = (k,p,r)  stages 0-2  base_eff = base

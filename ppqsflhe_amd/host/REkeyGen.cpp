@@ -23,7 +23,7 @@ int main(int argc, char *argv[]) {
         const uint32_t N = s.N(), D = s.D(), beta = s.beta();
         std::vector<uint64_t> sk, pk;
         std::vector<int8_t> sk_t;
-        if (!read_key_file(sk_path, KIND_SK, N, D, 1, sk, &sk_t)) {
+        if (!load_secret_key(s, sk_path, sk, sk_t)) {
             std::cerr << "Error loading Client private key from " << sk_path << std::endl;
             return 1;
         }

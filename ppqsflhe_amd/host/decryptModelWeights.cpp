@@ -21,10 +21,10 @@ int main(int argc, char *argv[]) {
     try {
         Session s(cc);
         std::cout << "[decrypt] CryptoContext loaded\n";
-        const uint32_t N = s.N(), D = s.D();
+        const uint32_t N = s.N();
         std::vector<uint64_t> sk;
         std::vector<int8_t> sk_t;
-        if (!read_key_file(privkey_path, KIND_SK, N, D, 1, sk, &sk_t)) {
+        if (!load_secret_key(s, privkey_path, sk, sk_t)) {
             std::cerr << "[decrypt] ERROR: Failed to load private key from " << privkey_path << std::endl;
             return 1;
         }

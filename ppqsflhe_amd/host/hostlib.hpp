@@ -244,6 +244,81 @@ private:
 };
 
 // ------------------------------------------------------------------------------------------------
+// Secret key: this project's container, or a private key written by OpenFHE's
+// Serial::SerializeToFile(path, kp.secretKey, SerType::JSON) (keyGen.cpp:45; fixture client_1-private.key:
+// value0.ptr_wrapper.data.s = DCRTPoly{v:[{v:{ptr_wrapper:{data:{v:[residues], m:{v:modulus}}}}, f:format}], f}).
+// Import: the Q limbs are checked against the context, limb 0 is brought to COEFFICIENT form on the device, the
+// coefficients must be ternary and every other limb must agree with them; the key over all D = L + K limbs is then
+// rebuilt from the ternary polynomial (OpenFHE stores s over Q only, hybrid re-key generation needs it over QP).
+// ------------------------------------------------------------------------------------------------
+inline bool import_openfhe_secret_key(Session &s, const std::string &path, std::vector<uint64_t> &sk,
+                                      std::vector<int8_t> &sk_t) {
+    Json j;
+    try {
+        j = Json::parse_file(path);
+    } catch (const std::exception &) {
+        return false;
+    }
+    if (!j.contains("value0")) return false;
+    const Json &poly = j.at("value0").at("ptr_wrapper").at("data").at("s");
+    const uint32_t N = s.N(), L = s.L(), D = s.D();
+    const std::vector<Json> &limbs = poly.at("v").a;
+    if (limbs.size() != L) throw std::runtime_error("private key: limb count differs from the CryptoContext");
+    const bool eval = limbs[0].at("f").as_int() == 0;
+    std::vector<uint64_t> res((size_t)L * N);
+    for (uint32_t i = 0; i < L; ++i) {
+        const Json &dat = limbs[i].at("v").at("ptr_wrapper").at("data");
+        const Json &mod = dat.at("m").at("v");
+        const uint64_t m = mod.kind == Json::Str ? std::stoull(mod.as_string()) : mod.as_u64();
+        if (m != s.moduli()[i]) throw std::runtime_error("private key: modulus differs from the CryptoContext");
+        if ((limbs[i].at("f").as_int() == 0) != eval) throw std::runtime_error("private key: mixed limb formats");
+        const std::vector<Json> &v = dat.at("v").a;
+        if (v.size() != N) throw std::runtime_error("private key: ring dimension differs from the CryptoContext");
+        for (uint32_t k = 0; k < N; ++k) {
+            const uint64_t r = v[k].kind == Json::Str ? std::stoull(v[k].as_string()) : v[k].as_u64();
+            if (r >= m) throw std::runtime_error("private key: residue out of range");
+            res[(size_t)i * N + k] = r;
+        }
+    }
+    uint64_t *d_res = s.to_device(res.data(), res.size());
+    if (eval) Session::check(mkckks_ntt_inverse_batch(s.ctx(), d_res, 1, L, 0));
+    s.to_host(res.data(), d_res, res.size());
+    sk_t.resize(N);
+    for (uint32_t k = 0; k < N; ++k) {
+        const uint64_t c = res[k], q0 = s.moduli()[0];
+        if (c > 1 && c != q0 - 1) throw std::runtime_error("private key: not a ternary secret");
+        sk_t[k] = c == 0 ? 0 : (c == 1 ? 1 : -1);
+        for (uint32_t i = 1; i < L; ++i) {
+            const uint64_t want = sk_t[k] == 0 ? 0 : (sk_t[k] == 1 ? 1 : s.moduli()[i] - 1);
+            if (res[(size_t)i * N + k] != want) throw std::runtime_error("private key: limbs disagree");
+        }
+    }
+    // NTT of the ternary polynomial over all D limbs: KeyGen's s-path with a = 0, e = 0 (the pk half is discarded)
+    std::vector<uint64_t> zeros_a((size_t)D * N, 0);
+    std::vector<int32_t> zeros_e(N, 0);
+    uint64_t *d_pk = s.alloc<uint64_t>((size_t)2 * D * N), *d_sk = s.alloc<uint64_t>((size_t)D * N);
+    Session::check(mkckks_keygen(s.ctx(), s.to_device(sk_t.data(), N), s.to_device(zeros_a.data(), zeros_a.size()),
+                                 s.to_device(zeros_e.data(), N), d_pk, d_sk));
+    sk.resize((size_t)D * N);
+    s.to_host(sk.data(), d_sk, sk.size());
+    if (eval)  // the rebuilt Q limbs must reproduce the file bit for bit
+        for (uint32_t i = 0; i < L; ++i) {
+            const Json &dat = limbs[i].at("v").at("ptr_wrapper").at("data");
+            const std::vector<Json> &v = dat.at("v").a;
+            for (uint32_t k = 0; k < N; k += 97) {
+                const uint64_t r = v[k].kind == Json::Str ? std::stoull(v[k].as_string()) : v[k].as_u64();
+                if (sk[(size_t)i * N + k] != r) throw std::runtime_error("private key: transform convention mismatch");
+            }
+        }
+    return true;
+}
+
+inline bool load_secret_key(Session &s, const std::string &path, std::vector<uint64_t> &sk, std::vector<int8_t> &sk_t) {
+    if (read_key_file(path, KIND_SK, s.N(), s.D(), 1, sk, &sk_t)) return true;
+    return import_openfhe_secret_key(s, path, sk, sk_t);
+}
+
+// ------------------------------------------------------------------------------------------------
 // weights_summary envelope helpers: the ciphertext fields of one file in a fixed order
 // ------------------------------------------------------------------------------------------------
 struct CtRef {

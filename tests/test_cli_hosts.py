@@ -164,3 +164,110 @@ def test_full_round_through_the_binaries(tmp_path, golden_dir):
     name = bad["layer"]
     v = (W[f"sample_c1_{name}_values"] + W[f"sample_c2_{name}_values"]) / 2
     assert np.abs(np.array(bad["values"]) - v).max() > 1.0
+
+
+def openfhe_style_private_key(limbs, moduli):
+    """The nesting of a private key written by Serial::SerializeToFile(.., SerType::JSON) (keyGen.cpp:45;
+    client_1-private.key): only the fields an importer needs, filled from the NTT-KAT fixture residues."""
+    v = [{"cereal_class_version": 1,
+          "v": {"polymorphic_id": 1073741824,
+                "ptr_wrapper": {"valid": 1, "data": {"cereal_class_version": 1, "v": [int(x) for x in limb],
+                                                     "m": {"v": int(m)}}}},
+          "f": 0} for limb, m in zip(limbs, moduli)]
+    return {"value0": {"polymorphic_id": 1073741824,
+                       "ptr_wrapper": {"id": 2147483649, "data": {"cereal_class_version": 0,
+                                                                  "s": {"cereal_class_version": 1, "v": v, "f": 0}}}}}
+
+
+def write_key_container(path, kind, ring_dim, limbs, parts, data):
+    """ppqsflhe_amd/host/hostlib.hpp BlobHeader (48 bytes) + raw residues."""
+    import struct
+    hdr = struct.pack("<4sIIIIIIIdII", b"MKCK", 1, kind, ring_dim, limbs, parts, 0, 0, 0.0, 0, 0)
+    assert len(hdr) == 48
+    with open(path, "wb") as f:
+        f.write(hdr)
+        f.write(np.ascontiguousarray(data, dtype=np.uint64).tobytes())
+
+
+@pytest.mark.gpu
+def test_private_key_written_by_openfhe_is_imported(tmp_path, golden_dir):
+    """REkeyGen / decryptModelWeights take the reference's own private-key file
+    (client/storage/client_1/private/client_1-private.key, committed as the NTT-KAT fixture): the ternary secret is
+    recovered from the EVALUATION limbs, the key is rebuilt over QP, and it decrypts what the matching public key
+    encrypted -- directly and after a domain change to a second client."""
+    import torch
+    from oracle.oracle import OracleContext
+    from ppqsflhe_amd import Context
+
+    ref = json.load(open(os.path.join(golden_dir, "cc_params.json")))
+    kat = np.load(os.path.join(golden_dir, "sk_ntt_kat.npz"))
+    sk_eval, sk_mod = kat["sk1_eval"], kat["sk1_moduli"]
+    assert [int(m) for m in sk_mod] == ref["moduli"]
+    cc = tmp_path / "CC.json"
+    cc.write_text(json.dumps(openfhe_style_cc(ref)))
+    skfile = tmp_path / "client_1-private.key"
+    skfile.write_text(json.dumps(openfhe_style_private_key(sk_eval, sk_mod)))
+
+    # the matching public key: ternary secret from the fixture (CPU oracle INTT), pk = (-a s + e, a) on the engine
+    log_n = int(np.log2(ref["ring_dim"]))
+    o = OracleContext(log_n, ref["mult_depth"], ref["scaling_bits"], 60, dnum=ref["dnum"])
+    coef = o.ntt_inv(0, sk_eval[0])
+    q0 = int(sk_mod[0])
+    s = np.where(coef == 0, 0, np.where(coef == 1, 1, -1)).astype(np.int8)
+    assert np.all((coef == 0) | (coef == 1) | (coef == q0 - 1))
+    ctx = Context(log_n, ref["mult_depth"], ref["scaling_bits"], 60, dnum=ref["dnum"], device=0)
+    N, D = ctx.N, ctx.D
+    dev = torch.device("cuda", 0)
+    a = torch.empty(D, N, dtype=torch.int64, device=dev)
+    e = torch.empty(N, dtype=torch.int32, device=dev)
+    ctx.sample_uniform(a, 1, ctx.L, True, 77, 0)
+    ctx.sample_gauss(e, N, 3.19, 77, 1)
+    pk = torch.empty(2, D, N, dtype=torch.int64, device=dev)
+    sk_dev = torch.empty(D, N, dtype=torch.int64, device=dev)
+    ctx.keygen(torch.from_numpy(s).to(dev), a, e, pk, sk_dev)
+    ctx.sync()
+    # the engine's transform of the recovered secret reproduces the file's limbs bit for bit
+    assert np.array_equal(sk_dev[:ctx.L].cpu().numpy().view(np.uint64), sk_eval)
+    write_key_container(tmp_path / "pk1", 2, N, D, 2, pk.cpu().numpy().view(np.uint64))
+    ctx.close()
+
+    W = np.load(os.path.join(golden_dir, "e2e_weights.npz"))
+    vals = W["sample_c1_param_2_values"]
+    wfile = tmp_path / "w.json"
+    wfile.write_text(json.dumps({"weights_summary": [{"layer": "param_2", "shape": [int(vals.size)],
+                                                      "mean": float(vals.mean()), "std_dev": float(vals.std()),
+                                                      "values": [float(v) for v in vals]}]}))
+
+    def ok(r):
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r
+
+    ok(run("encryptModelWeights", cc, tmp_path / "pk1", wfile, tmp_path / "enc1.json"))
+    r = ok(run("decryptModelWeights", cc, skfile, tmp_path / "enc1.json", tmp_path / "dec1.json"))
+    assert "[decrypt] Private key loaded" in r.stdout
+    got = np.array(json.load(open(tmp_path / "dec1.json"))["weights_summary"][0]["values"])
+    assert np.abs(got - vals).max() < 2.0 ** -25
+    # domain change c1 -> c2 with a re-key generated from the imported key (needs s over QP)
+    ok(run("keyGen", cc, tmp_path / "pk2", tmp_path / "sk2"))
+    ok(run("REkeyGen", cc, skfile, tmp_path / "pk2", tmp_path / "rk1"))
+    ok(run("changeCipherDomain", cc, tmp_path / "rk1", tmp_path / "enc1.json", tmp_path / "c1_as_c2.json"))
+    ok(run("decryptModelWeights", cc, tmp_path / "sk2", tmp_path / "c1_as_c2.json", tmp_path / "dec2.json"))
+    got = np.array(json.load(open(tmp_path / "dec2.json"))["weights_summary"][0]["values"])
+    assert np.abs(got - vals).max() < 2.0 ** -25
+    # a tampered file (one residue changed) is rejected, exit 1
+    bad = openfhe_style_private_key(sk_eval, sk_mod)
+    bad["value0"]["ptr_wrapper"]["data"]["s"]["v"][1]["v"]["ptr_wrapper"]["data"]["v"][5] ^= 1
+    badfile = tmp_path / "bad.key"
+    badfile.write_text(json.dumps(bad))
+    r = run("decryptModelWeights", cc, badfile, tmp_path / "enc1.json", tmp_path / "x.json")
+    assert r.returncode == 1 and "[decrypt] ERROR" in r.stderr
+
+
+def test_garbage_private_key_exits_1_without_gpu(tmp_path, golden_dir):
+    # decryptModelWeights.cpp:45-49: an unreadable key is "[decrypt] ERROR ..." + exit 1 (here also when no device)
+    ref = json.load(open(os.path.join(golden_dir, "cc_params.json")))
+    cc = tmp_path / "CC.json"
+    cc.write_text(json.dumps(openfhe_style_cc(ref)))
+    (tmp_path / "junk.key").write_text("not a key")
+    r = run("decryptModelWeights", cc, tmp_path / "junk.key", tmp_path / "a", tmp_path / "b")
+    assert r.returncode == 1 and "[decrypt] ERROR" in r.stderr

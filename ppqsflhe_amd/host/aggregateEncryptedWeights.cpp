@@ -27,7 +27,13 @@ int main(int argc, char *argv[]) {
         std::cout << "[agg] CryptoContext loaded\n";
         const uint32_t N = s.N();
         std::vector<Json> files;
-        for (const std::string &p : in_paths) files.push_back(Json::parse_file(p));
+        bool binary = false;  // the output keeps the first input's envelope form
+        for (const std::string &p : in_paths) {
+            bool b = false;
+            files.push_back(read_envelope(p, &b));
+            if (files.size() == 1) binary = b;
+        }
+        raw_blobs() = binary;
         const size_t n_files = files.size();
 
         // match layers: for each layer of file 0 (client 2) the same layer+shape in every other file
@@ -112,7 +118,7 @@ int main(int argc, char *argv[]) {
                 else lay["values"].a[items[b].idx] = Json(std::move(b64));
             }
         }
-        outputJson.write_file(output_file);
+        write_envelope(outputJson, output_file, binary);
     } catch (const std::exception &e) {
         std::cerr << "[agg] ERROR: " << e.what() << std::endl;
         return 1;

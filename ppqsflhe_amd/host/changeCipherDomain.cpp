@@ -29,8 +29,10 @@ int main(int argc, char *argv[]) {
         }
         std::cout << "[recrypt] ReKey loaded\n";
         Json inputJson;
+        bool binary = false;  // the output keeps the input's envelope form
         try {
-            inputJson = Json::parse_file(input_encfile);
+            inputJson = read_envelope(input_encfile, &binary);
+            raw_blobs() = binary;
         } catch (const std::exception &) {
             std::cerr << "[recrypt] ERROR: Could not open input encrypted weights file\n";
             return 1;
@@ -61,7 +63,7 @@ int main(int argc, char *argv[]) {
             }
         }
         try {
-            outputJson.write_file(output_encfile);
+            write_envelope(outputJson, output_encfile, binary);
         } catch (const std::exception &) {
             std::cerr << "[recrypt] ERROR: Failed to open output file\n";
             return 1;

@@ -31,7 +31,7 @@ int main(int argc, char *argv[]) {
         std::cout << "[decrypt] Private key loaded\n";
         Json encJson;
         try {
-            encJson = Json::parse_file(input_encfile);
+            encJson = read_envelope(input_encfile);
         } catch (const std::exception &) {
             std::cerr << "[decrypt] ERROR: Could not open input file: " << input_encfile << std::endl;
             return 1;

@@ -40,6 +40,7 @@ int main(int argc, char *argv[]) {
             return 1;
         }
         std::cout << "[encrypt] Weights loaded from " << input_weights << std::endl;
+        raw_blobs() = wants_binary_output(output_encfile);  // MKCKKS_ENVELOPE=binary or a ".mkws" output path
 
         // gather every plaintext vector of the file
         struct Slot { size_t layer; int field; };
@@ -104,7 +105,7 @@ int main(int argc, char *argv[]) {
             enc["values"] = arr;
         }
         try {
-            outputJson.write_file(output_encfile);
+            write_envelope(outputJson, output_encfile, raw_blobs());
         } catch (const std::exception &) {
             std::cerr << "[encrypt] ERROR: Failed to write to output file: " << output_encfile << std::endl;
             return 1;

@@ -116,6 +116,13 @@ struct Ciphertext {
     std::vector<uint64_t> data;  // [2][nl][N]
 };
 
+// Binary envelope: when set, ciphertext fields hold the raw container bytes in memory (no
+// base64) and write_envelope() stores them behind the JSON skeleton; see read_envelope / write_envelope below.
+inline bool &raw_blobs() {
+    static bool on = false;
+    return on;
+}
+
 inline std::string encode_ct(const Ciphertext &ct, uint32_t ring_dim) {
     BlobHeader h{};
     std::memcpy(h.magic, "MKCK", 4);
@@ -124,11 +131,14 @@ inline std::string encode_ct(const Ciphertext &ct, uint32_t ring_dim) {
     std::string bin(sizeof h + ct.data.size() * 8, '\0');
     std::memcpy(&bin[0], &h, sizeof h);
     std::memcpy(&bin[sizeof h], ct.data.data(), ct.data.size() * 8);
-    return Base64Encode(bin);
+    return raw_blobs() ? bin : Base64Encode(bin);
 }
 
 inline Ciphertext decode_ct(const std::string &b64, uint32_t ring_dim) {
-    std::string bin = Base64Decode(b64);
+    // a raw container starts with the magic itself; its base64 form starts with "TUtD"
+    const bool raw = b64.size() >= 4 && !std::memcmp(b64.data(), "MKCK", 4);
+    const std::string decoded = raw ? std::string() : Base64Decode(b64);
+    const std::string &bin = raw ? b64 : decoded;
     if (bin.size() < sizeof(BlobHeader)) throw std::runtime_error("ciphertext blob too short");
     BlobHeader h;
     std::memcpy(&h, bin.data(), sizeof h);
@@ -342,6 +352,108 @@ inline const std::string &ct_string(const Json &file, const CtRef &r) {
     if (r.field == 0) return lay.at("mean").as_string();
     if (r.field == 1) return lay.at("std_dev").as_string();
     return lay.at("values").at(r.idx).as_string();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Envelope files.  JSON form: the reference's weights_summary document with base64 ciphertext strings
+// (aggregateEncryptedWeights.cpp:64-65,119).  Binary form ("MKWS"): the same document with every ciphertext string
+// replaced by "@<index>", followed by the raw ciphertext containers -- no base64 (x4/3) and no JSON string
+// escaping/parsing of hundreds of MiB.  Layout: magic "MKWS", u32 version = 1, u64 skeleton bytes, skeleton JSON,
+// u64 blob count, then per blob u64 size + bytes.  Readers detect the form from the first four bytes; writers
+// follow the input's form (encryptModelWeights: MKCKKS_ENVELOPE=binary, or an output path ending in ".mkws").
+// ------------------------------------------------------------------------------------------------
+template <typename F>
+inline void for_each_ct_field(Json &file, F &&fn) {
+    for (Json &lay : file["weights_summary"].a) {
+        if (lay.contains("mean") && lay.at("mean").is_string()) fn(lay["mean"]);
+        if (lay.contains("std_dev") && lay.at("std_dev").is_string()) fn(lay["std_dev"]);
+        if (lay.contains("values"))
+            for (Json &v : lay["values"].a)
+                if (v.is_string()) fn(v);
+    }
+}
+
+inline bool wants_binary_output(const std::string &out_path) {
+    const char *e = std::getenv("MKCKKS_ENVELOPE");
+    if (e && std::string(e) == "binary") return true;
+    if (e && std::string(e) == "json") return false;
+    return out_path.size() > 5 && out_path.compare(out_path.size() - 5, 5, ".mkws") == 0;
+}
+
+inline Json read_envelope(const std::string &path, bool *was_binary = nullptr) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    char magic[4] = {0, 0, 0, 0};
+    const bool bin = std::fread(magic, 1, 4, f) == 4 && !std::memcmp(magic, "MKWS", 4);
+    if (was_binary) *was_binary = bin;
+    if (!bin) {
+        std::fclose(f);
+        return Json::parse_file(path);
+    }
+    auto fail = [&](const char *why) {
+        std::fclose(f);
+        throw std::runtime_error(std::string("binary envelope: ") + why);
+    };
+    uint32_t version = 0;
+    uint64_t skel_len = 0, n_blobs = 0;
+    if (std::fread(&version, 4, 1, f) != 1 || version != 1) fail("unsupported version");
+    if (std::fread(&skel_len, 8, 1, f) != 1 || skel_len > (1ull << 32)) fail("bad skeleton size");
+    std::string skel(skel_len, '\0');
+    if (skel_len && std::fread(&skel[0], 1, skel_len, f) != skel_len) fail("truncated skeleton");
+    if (std::fread(&n_blobs, 8, 1, f) != 1 || n_blobs > (1ull << 32)) fail("bad blob count");
+    std::vector<std::string> blobs(n_blobs);
+    for (std::string &b : blobs) {
+        uint64_t sz = 0;
+        if (std::fread(&sz, 8, 1, f) != 1 || sz > (1ull << 36)) fail("bad blob size");
+        b.resize(sz);
+        if (sz && std::fread(&b[0], 1, sz, f) != sz) fail("truncated blob");
+    }
+    std::fclose(f);
+    Json doc = Json::parse(skel);
+    std::vector<bool> used(blobs.size(), false);
+    for_each_ct_field(doc, [&](Json &field) {
+        const std::string &ref = field.as_string();
+        if (ref.size() < 2 || ref[0] != '@') throw std::runtime_error("binary envelope: ciphertext field without a blob index");
+        const size_t i = std::stoull(ref.substr(1));
+        if (i >= blobs.size() || used[i]) throw std::runtime_error("binary envelope: blob index out of range or reused");
+        used[i] = true;
+        field = Json(std::move(blobs[i]));
+    });
+    return doc;
+}
+
+inline void write_envelope(const Json &doc, const std::string &path, bool binary) {
+    if (!binary) {
+        doc.write_file(path);
+        return;
+    }
+    Json skel = doc;
+    std::vector<std::string> blobs;
+    for_each_ct_field(skel, [&](Json &field) {
+        std::string ref = "@" + std::to_string(blobs.size());
+        blobs.push_back(field.as_string());
+        field = Json(std::move(ref));
+    });
+    for (const std::string &b : blobs)
+        if (b.size() < 4 || std::memcmp(b.data(), "MKCK", 4))
+            throw std::runtime_error("binary envelope: ciphertext field is not a raw container");
+    std::string text;
+    skel.dump(text, 2);
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write " + path);
+    const uint32_t version = 1;
+    const uint64_t skel_len = text.size(), n_blobs = blobs.size();
+    std::fwrite("MKWS", 1, 4, f);
+    std::fwrite(&version, 4, 1, f);
+    std::fwrite(&skel_len, 8, 1, f);
+    std::fwrite(text.data(), 1, text.size(), f);
+    std::fwrite(&n_blobs, 8, 1, f);
+    for (const std::string &b : blobs) {
+        const uint64_t sz = b.size();
+        std::fwrite(&sz, 8, 1, f);
+        std::fwrite(b.data(), 1, b.size(), f);
+    }
+    if (std::fclose(f) != 0) throw std::runtime_error("cannot write " + path);
 }
 
 }  // namespace mkh

@@ -158,6 +158,44 @@ def test_full_round_through_the_binaries(tmp_path, golden_dir):
             assert np.abs(got - (v1 + v2) / 2).max() < tol
             ms = (W[f"sample_c1_{name}_mean_std"] + W[f"sample_c2_{name}_mean_std"]) / 2
             assert abs(l["mean"] - ms[0]) < tol and abs(l["std_dev"] - ms[1]) < tol
+    # f1 binary envelope: the same ciphertexts carried as raw containers behind the JSON skeleton ("MKWS");
+    # the server programs keep the input's form, the decrypted document is identical to the JSON route's
+    def reenvelope(src, dst):
+        import base64, struct
+        doc = json.load(open(src))
+        blobs = []
+
+        def take(b64):
+            blobs.append(base64.b64decode(b64))
+            return f"@{len(blobs) - 1}"
+        for l in doc["weights_summary"]:
+            l["mean"], l["std_dev"] = take(l["mean"]), take(l["std_dev"])
+            l["values"] = [take(v) for v in l["values"]]
+        text = json.dumps(doc).encode()
+        with open(dst, "wb") as f:
+            f.write(b"MKWS" + struct.pack("<IQ", 1, len(text)) + text + struct.pack("<Q", len(blobs)))
+            for b in blobs:
+                f.write(struct.pack("<Q", len(b)) + b)
+    reenvelope(tmp_path / "enc1.json", tmp_path / "enc1.mkws")
+    reenvelope(tmp_path / "enc2.json", tmp_path / "enc2.mkws")
+    ok(run("changeCipherDomain", cc, tmp_path / "rk1", tmp_path / "enc1.mkws", tmp_path / "c1_as_c2.mkws"))
+    assert open(tmp_path / "c1_as_c2.mkws", "rb").read(4) == b"MKWS"
+    assert os.path.getsize(tmp_path / "c1_as_c2.mkws") < 0.8 * os.path.getsize(tmp_path / "c1_as_c2.json")
+    ok(run("aggregateEncryptedWeights", cc, tmp_path / "enc2.mkws", tmp_path / "c1_as_c2.mkws", tmp_path / "agg.mkws"))
+    ok(run("decryptModelWeights", cc, tmp_path / "sk2", tmp_path / "agg.mkws", tmp_path / "dec2_bin.json"))
+    assert json.load(open(tmp_path / "dec2_bin.json")) == json.load(open(tmp_path / "dec2.json"))  # PRE is deterministic
+    # encryptModelWeights writes the binary form on request; it decrypts like the JSON one
+    ok(run("encryptModelWeights", cc, tmp_path / "pk2", weights_file(2), tmp_path / "enc2b.mkws"))
+    assert open(tmp_path / "enc2b.mkws", "rb").read(4) == b"MKWS"
+    ok(run("decryptModelWeights", cc, tmp_path / "sk2", tmp_path / "enc2b.mkws", tmp_path / "dec2b.json"))
+    d2b = json.load(open(tmp_path / "dec2b.json"))["weights_summary"][0]
+    assert np.abs(np.array(d2b["values"]) - W[f"sample_c2_{d2b['layer']}_values"]).max() < tol
+    # truncated binary envelope -> exit 1
+    raw = open(tmp_path / "agg.mkws", "rb").read()
+    open(tmp_path / "trunc.mkws", "wb").write(raw[:len(raw) // 2])
+    r = run("decryptModelWeights", cc, tmp_path / "sk2", tmp_path / "trunc.mkws", tmp_path / "x.json")
+    assert r.returncode == 1 and "[decrypt] ERROR" in r.stderr
+
     # wrong key -> garbage, not the mean (sanity that decryption really depends on the domain change)
     ok(run("decryptModelWeights", cc, tmp_path / "sk1", tmp_path / "agg.json", tmp_path / "bad.json"))
     bad = json.load(open(tmp_path / "bad.json"))["weights_summary"][0]

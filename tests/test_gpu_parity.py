@@ -348,7 +348,10 @@ def test_reencrypt_accumulate(ctxs, name, nl):
 
 
 @pytest.mark.parametrize("name,nl,C,B", [("tiny", 5, 3, 2), ("tiny", 3, 1, 1), ("ref", 4, 2, 3), ("c3", 12, 3, 2),
-                                         ("c5s", 20, 2, 1), ("n11", 4, 3, 2), ("tiny", 5, 2, 19)])
+                                         ("c5s", 20, 2, 1), ("n11", 4, 3, 2), ("tiny", 5, 2, 19),
+                                         # the N=2^16 sum kernel takes clients two at a time: even / odd counts, one
+                                         # and two full pairs, a lower level (nl < L)
+                                         ("c3", 12, 4, 1), ("c3", 12, 5, 1), ("c3", 11, 2, 2), ("c3", 12, 1, 1)])
 def test_reencrypt_sum(ctxs, name, nl, C, B):
     # sum over clients of ReEncrypt(ct_c, evk_c) in one call == EvalAdd chain of the individual re-encryptions
     g, o = ctxs(name)

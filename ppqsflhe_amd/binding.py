@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libmkckks_hip.so")
+_LIB = os.environ.get("MKCKKS_LIB") or os.path.join(_HERE, "libmkckks_hip.so")  # override: A/B builds
 
 
 class MkckksError(RuntimeError):

@@ -196,16 +196,17 @@ MK_D void col_forward_finish(u64 (&x)[1 << LOG_H], u64 *lds, const u64 *tw, cons
                              int j, int c, u64 *dst_col, uint32_t r2) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H;
-    u64 w[H - 1], wp[H - 1];
+    u64 w[H - 1], wp[H - 1], w2[H - 1], wp2[H - 1];
     load_round_twiddles<LOG_H>(tw, tw_sh, 1u, w, wp);  // same for every column: scalar loads
     radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+    // second-round twiddles are requested BEFORE the exchange: their L2 latency runs under the barrier wait
+    load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w2, wp2);
 #pragma unroll
     for (int k = 0; k < H; ++k) lds[TL::at(k, j, c)] = x[k];  // row j + H k
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < H; ++k) x[k] = lds[TL::at(j, k, c)];  // row H j + k
-    load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w, wp);
-    radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+    radix_forward_any<LOG_H, FP>(x, w2, wp2, lc);
 #pragma unroll
     for (int k = 0; k < H; ++k) dst_col[(size_t)(H * j + k) * r2] = x[k];  // lazy u64, or doubles on an fp limb
 }
@@ -395,13 +396,14 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         __syncthreads();
         TA::fetch(twa, twa_sh, g, w, wp);
         radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+        u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
+        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w2, wp2);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
-        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);
-        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+        radix_forward_any<LOG_H, FP>(x, w2, wp2, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k)  // canonical u64, own words only
             lds[TL::at(g, H * j + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
@@ -440,6 +442,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
             }
         }
     } else {
+        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);  // first: in flight while the tile is staged
         for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
             const int gg = (2 * e) / R, xx = (2 * e) % R;
             const ulong2 v = reinterpret_cast<const ulong2 *>(src)[e];
@@ -454,7 +457,6 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
 #pragma unroll
             for (int k = 0; k < H; ++k) x[k] = dbits((double)x[k]);
         }
-        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);
         radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = x[k];
@@ -630,6 +632,8 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
             radix_forward_any<LOG_H, FP>(xa, w, wp, lc);
             radix_forward_any<LOG_H, FP>(xb, w, wp, lc);
         }
+        u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
+        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w2, wp2);
 #pragma unroll
         for (int k = 0; k < H; ++k) {
             lds[TL::at(g, j + H * k)] = xa[k];
@@ -641,12 +645,8 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
             xa[k] = lds[TL::at(g, H * j + k)];
             xb[k] = ldsb[TL::at(g, H * j + k)];
         }
-        {
-            u64 w[H - 1], wp[H - 1];
-            load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);
-            radix_forward_any<LOG_H, FP>(xa, w, wp, lc);
-            radix_forward_any<LOG_H, FP>(xb, w, wp, lc);
-        }
+        radix_forward_any<LOG_H, FP>(xa, w2, wp2, lc);
+        radix_forward_any<LOG_H, FP>(xb, w2, wp2, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) {
             lds[TL::at(g, H * j + k)] = FP ? fp_to_canonical(bitsd(xa[k]), lc.qd, lc.qinv) : canon8(xa[k], lc.q, lc.q2);

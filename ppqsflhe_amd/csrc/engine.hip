@@ -282,8 +282,8 @@ __global__ void k_baseconv(const u64 *in, size_t in_stride, u64 *out, size_t out
 template <int NPARTS>
 __global__ void k_inner_product_b(const u64 *digits, const u64 *c1, size_t c1_stride, const u64 *evk, u64 *ctilde,
                                   EwGeom g, const LimbConst *limb, uint32_t ext, uint32_t D, uint32_t alpha,
-                                  uint32_t items) {
-    const uint32_t slot = blockIdx.y;
+                                  uint32_t items, unsigned long long slot_mask) {
+    const uint32_t slot = nth_set_bit(slot_mask, blockIdx.y);  // the slots this launch covers
     const uint32_t idx = (blockIdx.x * EW_THREADS + threadIdx.x) * 2;
     if (idx >= g.n) return;
     const uint32_t id = limb_id_of(slot, g.nl, g.L);
@@ -731,14 +731,15 @@ static bool row_tail_supported(const NttTables &T) { return fast_row(T.log_r2, 1
 static bool row_sum_supported(const NttTables &T) { return fast_log_h(T.log_r2, 1u << T.log_r1) != 0; }
 
 template <bool INV>
-static void launch_row(const NttIo &io0, const NttTables &T, uint32_t n_polys, const TailArgs &tail, const Lanes &ln) {
+static void launch_row(const NttIo &io0, const NttTables &T, uint32_t n_polys, const TailArgs &tail, const Lanes &ln,
+                       unsigned classes = 3) {  // bit 0: integer limbs, bit 1: fp64 limbs
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     NttIo io = io0, iof = io0;
     io.slot_mask = class_mask(io0, T.h_fp_of, T.L, false);
     iof.slot_mask = class_mask(io0, T.h_fp_of, T.L, true);
     io.nsel = (uint32_t)__builtin_popcountll(io.slot_mask);
     iof.nsel = (uint32_t)__builtin_popcountll(iof.slot_mask);
-    const uint32_t items = n_polys * io.nsel, itemsf = n_polys * iof.nsel;
+    const uint32_t items = (classes & 1) ? n_polys * io.nsel : 0, itemsf = (classes & 2) ? n_polys * iof.nsel : 0;
     switch (fast_row(T.log_r2, r1)) {
         case 9:
             launch_two_classes(ln, items != 0, itemsf != 0,
@@ -993,7 +994,8 @@ const u64 *Engine::p_inverse(uint32_t nl) {
 
 // EvalKeySwitchPrecomputeCore on `cnt` polynomials c1 (items ct_stride apart): fills the converted limbs of
 // dig[item][part][ext][N] in EVALUATION format; the digits' own limbs are NOT copied (readers take them from c1).
-void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, uint32_t cnt, uint32_t nl) {
+void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, uint32_t cnt, uint32_t nl,
+                        bool rows_int_only) {
     const uint32_t n = ps_.n, ext = nl + ps_.K, nparts = ps_.num_parts(nl), D = ps_.D;
     const u64 *fold = folded_scale(nl);
     // the fused conversion kernel exists when the column pass has a radix kernel; it reads packed 30-bit halves
@@ -1010,10 +1012,12 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
     if (fused) {
         // S3b: one row pass over every converted limb of every digit (own limbs skipped)
         NttIo row{dig, dig, (size_t)ext * n, (size_t)ext * n, 0, 0, 0, ext, nl, nparts, ps_.alpha};
-        launch_row<false>(row, tabs_, cnt * nparts, TailArgs{}, lanes());
+        // (rows_int_only: the fp64 limbs finish their transform inside the fused inner-product kernel)
+        launch_row<false>(row, tabs_, cnt * nparts, TailArgs{}, lanes(), rows_int_only ? 1u : 3u);
         MK_HIP(hipGetLastError());
         return;
     }
+    if (rows_int_only) throw std::logic_error("fused inner product needs the radix kernels");
     for (uint32_t part = 0; part < nparts; ++part) {  // ring sizes without a radix column kernel
         const DevConv &cv = modup_conv(nl, part);
         const uint32_t lo = part * ps_.alpha, hi = lo + cv.n_in;
@@ -1094,13 +1098,73 @@ void Engine::moddown(const u64 *in, u64 *out, uint32_t cnt, uint32_t nl) {
 
 template <int NPARTS>
 static void launch_inner(const u64 *dig, const u64 *c1, size_t c1_stride, const u64 *evk, u64 *til, EwGeom g,
-                         const LimbConst *limb, uint32_t ext, uint32_t D, uint32_t alpha, uint32_t items, hipStream_t s) {
-    k_inner_product_b<NPARTS><<<dim3((g.n / 2 + EW_THREADS - 1) / EW_THREADS, ext), EW_THREADS, 0, s>>>(
-        dig, c1, c1_stride, evk, til, g, limb, ext, D, alpha, items);
+                         const LimbConst *limb, uint32_t ext, uint32_t D, uint32_t alpha, uint32_t items,
+                         unsigned long long slot_mask, hipStream_t s) {
+    const uint32_t nsel = (uint32_t)__builtin_popcountll(slot_mask);
+    if (!nsel) return;
+    k_inner_product_b<NPARTS><<<dim3((g.n / 2 + EW_THREADS - 1) / EW_THREADS, nsel), EW_THREADS, 0, s>>>(
+        dig, c1, c1_stride, evk, til, g, limb, ext, D, alpha, items, slot_mask);
+}
+
+template <int LOG_H, int NPARTS>
+static void launch_row_inner_fp(const InnerArgs &a, const NttTables &T, hipStream_t s) {
+    const uint32_t tiles = (1u << T.log_r1) / (256u >> LOG_H);
+    // 2 waves per SIMD: 196 VGPRs, no spills; measured 18.35 k ct/s against 17.9 k at 3 waves (168 VGPRs, 28 spilled)
+    static const int waves = [] { const char *e = std::getenv("MKCKKS_INNER_WAVES"); return e ? std::atoi(e) : 2; }();
+    const dim3 grid(tiles * a.nsel * a.items);
+    if (waves == 3) k_row_inner_fp<LOG_H, NPARTS, 3><<<grid, NTT_THREADS, 0, s>>>(a, T);
+    else k_row_inner_fp<LOG_H, NPARTS, 2><<<grid, NTT_THREADS, 0, s>>>(a, T);
+}
+template <int LOG_H>
+static void launch_row_inner_fp_n(const InnerArgs &a, const NttTables &T, uint32_t nparts, hipStream_t s) {
+    switch (nparts) {
+        case 1: launch_row_inner_fp<LOG_H, 1>(a, T, s); break;
+        case 2: launch_row_inner_fp<LOG_H, 2>(a, T, s); break;
+        case 3: launch_row_inner_fp<LOG_H, 3>(a, T, s); break;
+        case 4: launch_row_inner_fp<LOG_H, 4>(a, T, s); break;
+        case 5: launch_row_inner_fp<LOG_H, 5>(a, T, s); break;
+        case 6: launch_row_inner_fp<LOG_H, 6>(a, T, s); break;
+        default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
+    }
+}
+
+// S1-S4 of the hybrid key switch for `cnt` ciphertexts: ModUp digits of c1 (EvalKeySwitchPrecomputeCore) and their
+// inner product with the eval key over Q_l P (EvalFastKeySwitchCoreExt) -> til [cnt][2][ext][N].
+// With the radix kernels the fp64 Q limbs finish their forward transform inside k_row_inner_fp (digits stay on chip);
+// integer limbs (q0, P) take the row pass + k_inner_product_b, which keeps the eval key in registers across the batch.
+void Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u64 *coef, u64 *dig, u64 *til,
+                              uint32_t cnt, uint32_t nl) {
+    const uint32_t n = ps_.n, ext = nl + ps_.K, nparts = ps_.num_parts(nl), D = ps_.D;
+    static const bool fuse_env = [] { const char *e = std::getenv("MKCKKS_FUSE_INNER"); return !e || std::atoi(e) != 0; }();
+    const int row_h = fast_log_h(tabs_.log_r2, 1u << tabs_.log_r1);
+    unsigned long long fp_mask = 0, all_mask = ext >= 64 ? ~0ull : ((1ull << ext) - 1);
+    for (uint32_t i = 0; i < nl; ++i)
+        if (tabs_.h_fp_of[i]) fp_mask |= 1ull << i;
+    const bool fuse = fuse_env && fp_mask != 0 && (row_h == 3 || row_h == 4) &&
+                      fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0;
+    modup_core(c1, ct_stride, coef, dig, cnt, nl, fuse);
+    if (fuse) {
+        InnerArgs a{dig, c1, evk, til, ct_stride, nl, ext, D, ps_.alpha, cnt, fp_mask,
+                    (uint32_t)__builtin_popcountll(fp_mask)};
+        if (row_h == 4) launch_row_inner_fp_n<4>(a, tabs_, nparts, stream_);
+        else launch_row_inner_fp_n<3>(a, tabs_, nparts, stream_);
+    }
+    const unsigned long long mask = fuse ? (all_mask & ~fp_mask) : all_mask;
+    EwGeom g{n, nl, ps_.L};
+    switch (nparts) {
+        case 1: launch_inner<1>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, mask, stream_); break;
+        case 2: launch_inner<2>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, mask, stream_); break;
+        case 3: launch_inner<3>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, mask, stream_); break;
+        case 4: launch_inner<4>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, mask, stream_); break;
+        case 5: launch_inner<5>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, mask, stream_); break;
+        case 6: launch_inner<6>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, mask, stream_); break;
+        default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
+    }
+    MK_HIP(hipGetLastError());
 }
 
 void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t cnt, uint32_t nl, bool accumulate) {
-    const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, nparts = ps_.num_parts(nl), D = ps_.D;
+    const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, nparts = ps_.num_parts(nl);
     const size_t ct_stride = (size_t)2 * nl * n;
     const size_t w_coef = (size_t)cnt * nl * n, w_dig = (size_t)cnt * nparts * ext * n;
     const size_t w_til = (size_t)cnt * 2 * ext * n, w_pc = (size_t)cnt * 2 * K * n, w_conv = (size_t)cnt * 2 * nl * n;
@@ -1108,21 +1172,8 @@ void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t c
     u64 *coef = ws, *dig = coef + w_coef, *til = dig + w_dig, *pc = til + w_til, *conv = pc + w_pc;
     const u64 *c1 = ct + (size_t)nl * n;  // component 1 of item 0; items are ct_stride apart
 
-    // S1-S3: ModUp digits of c1 (EvalKeySwitchPrecomputeCore)
-    modup_core(c1, ct_stride, coef, dig, cnt, nl);
-    // S4: inner product with the eval key over Q_l P (EvalFastKeySwitchCoreExt); the eval key stays in
-    // registers across the batch, own limbs come straight from c1
-    EwGeom g{n, nl, ps_.L};
-    switch (nparts) {
-        case 1: launch_inner<1>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
-        case 2: launch_inner<2>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
-        case 3: launch_inner<3>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
-        case 4: launch_inner<4>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
-        case 5: launch_inner<5>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
-        case 6: launch_inner<6>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
-        default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
-    }
-    MK_HIP(hipGetLastError());
+    // S1-S4: ModUp digits of c1 and their inner product with the eval key
+    keyswitch_digits(c1, ct_stride, evk, coef, dig, til, cnt, nl);
     // S5: ApproxModDown of both components (2*cnt polynomials of ext limbs), + c0 on component 0
     moddown_core(til, pc, conv, out, (size_t)nl * n, ct, ct_stride, 2 * cnt, nl, accumulate);
 }
@@ -1209,18 +1260,7 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
                 u64 *til = til0 + (size_t)c * w_til, *conv = conv0 + (size_t)c * w_conv;
                 const u64 *ct = cts + ((size_t)c * n_ct + b0) * ct_words, *evk = evks + (size_t)c * evk_words;
                 const u64 *c1 = ct + (size_t)nl * n;
-                modup_core(c1, ct_words, coef, dig, cnt, nl);
-                EwGeom g{n, nl, ps_.L};
-                switch (nparts) {
-                    case 1: launch_inner<1>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
-                    case 2: launch_inner<2>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
-                    case 3: launch_inner<3>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
-                    case 4: launch_inner<4>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
-                    case 5: launch_inner<5>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
-                    case 6: launch_inner<6>(dig, c1, ct_words, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, stream_); break;
-                    default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
-                }
-                MK_HIP(hipGetLastError());
+                keyswitch_digits(c1, ct_words, evk, coef, dig, til, cnt, nl);
                 // ModDown up to the column pass of the converted limbs
                 NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
                 ntt_passes(s5, tabs_, 2 * cnt, true, fold, fold + D, lanes(), 1);

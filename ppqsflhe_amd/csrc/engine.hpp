@@ -114,7 +114,10 @@ private:
     void reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl, bool accumulate);
     const u64 *folded_scale(uint32_t nl);
     const u64 *p_inverse(uint32_t nl);
-    void modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, uint32_t cnt, uint32_t nl);
+    void modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, uint32_t cnt, uint32_t nl,
+                    bool rows_int_only = false);
+    void keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u64 *coef, u64 *dig, u64 *til, uint32_t cnt,
+                          uint32_t nl);
     void moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t out_stride, const u64 *add,
                       size_t add_stride, uint32_t cnt, uint32_t nl, bool accumulate);
 

@@ -141,6 +141,21 @@ MK_D u64 fp_to_canonical(double x, double q, double qinv) {
     r = r < 0.0 ? r + q : r;
     return (u64)r;
 }
+// y*e mod q for an arbitrary (not precomputed) factor e in [0,q), |y| <= q: the quotient is estimated from the
+// rounded product (relative error <= 1.5*2^-52, i.e. <= 0.47 units at |y| = q < 1.25*2^50), so the result is the
+// exact integer y*e - b*q with |result| <= 0.97 q (<= 0.75 q when |y| <= 0.51 q); the fma's true value is an
+// integer below 2^52 and therefore exact
+MK_D double fp_mulmod_any(double y, double e, double q, double qinv) {
+    const double h = __dmul_rn(y, e);
+    const double l = __fma_rn(y, e, -h);
+    const double b = rint(__dmul_rn(h, qinv));
+    const double c = __fma_rn(-b, q, h);
+    return __dadd_rn(c, l);
+}
+// exact conversion of an integer below 2^52 (splice it into the mantissa of 2^52, subtract 2^52)
+MK_D double u52_to_double(u64 v) {
+    return __longlong_as_double((long long)(v | 0x4330000000000000ull)) - 4503599627370496.0;
+}
 MK_D u64 dbits(double d) { return (u64)__double_as_longlong(d); }
 MK_D double bitsd(u64 b) { return __longlong_as_double((long long)b); }
 #endif

@@ -699,6 +699,131 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
     for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[threadIdx.x + i * NTT_THREADS] = acc[i];
 }
 
+// ModUp row pass + inner product with the eval key in ONE kernel, fp64 limbs only (EvalKeySwitchPrecomputeCore's
+// SetFormat(EVALUATION) + EvalFastKeySwitchCoreExt, keyswitch-hybrid.cpp): for a (ciphertext, Q limb t, row tile) the
+// workgroup finishes the forward transform of every converted digit d_j[t] and accumulates d_j[t] * b_j[t] and
+// d_j[t] * a_j[t] in registers (exact doubles, fp_mulmod_any); the digit that owns t comes straight from c1.  The
+// transformed digits never go to HBM: per ciphertext and limb this saves (beta-1) limb writes + beta limb reads.
+struct InnerArgs {
+    const u64 *dig;      // [item][nparts][ext][N] column-passed converted limbs (doubles on fp limbs)
+    const u64 *c1;       // component 1 of the input ciphertexts, items c1_stride words apart: [nl][N] canonical
+    const u64 *evk;      // [nparts][2][D][N]
+    u64 *til;            // [item][2][ext][N]
+    size_t c1_stride;
+    uint32_t nl, ext, D, alpha, items;
+    unsigned long long slot_mask;  // fp-class Q limbs
+    uint32_t nsel;
+};
+template <int LOG_H, int NPARTS, int WAVES>
+__global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a, NttTables T) {
+    using TL = RowTile<LOG_H>;
+    using TA = RowTwA<LOG_H>;
+    constexpr int H = TL::H, S = TL::S, R = TL::R, PAIRS = S * R / 2 / NTT_THREADS;
+    __shared__ u64 lds[TL::WORDS + 2 * TA::WORDS];
+    u64 *twa = lds + TL::WORDS, *twa_sh = twa + TA::WORDS;
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
+    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
+    uint32_t grp, item;
+    if (groups % 8 == 0) {  // the items of one (limb, tile) share its eval-key and twiddle tiles: same XCD, consecutive
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / a.items) * 8 + xcd;
+        item = qidx % a.items;
+    } else {
+        grp = blockIdx.x / a.items;
+        item = blockIdx.x % a.items;
+    }
+    const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);  // Q limb: slot == limb id
+    const LimbConst lc = T.limb[sl];
+    const int own = (int)(sl / a.alpha);
+    const uint32_t row0 = (grp % tiles) * S;
+    const int g = threadIdx.x / H, j = threadIdx.x % H;
+    const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
+    const uint32_t base = r1 + row0 + g;
+    const size_t tile_off = (size_t)row0 * R;
+    const double q = lc.qd, qinv = lc.qinv;
+    TA::stage(twa, twa_sh, tw, tw_sh, r1 + row0);  // round-A twiddles are the same for every digit
+    int jn = own == 0 ? 1 : 0;  // first converted digit
+    const u64 *dig0 = a.dig + ((size_t)item * NPARTS * a.ext + sl) * n + tile_off + (size_t)g * R + j;
+    u64 x[H];
+    if (jn < NPARTS) {
+        const u64 *src = dig0 + (size_t)jn * a.ext * n;
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = src[H * k];
+    }
+    double2 acc0[PAIRS], acc1[PAIRS];
+    {   // the digit that owns this limb: c1 itself, already in EVALUATION format
+        const u64 *y0 = a.c1 + (size_t)item * a.c1_stride + (size_t)sl * n + tile_off;
+        const u64 *e0 = a.evk + (((size_t)own * 2 + 0) * a.D + sl) * n + tile_off;
+        const u64 *e1 = a.evk + (((size_t)own * 2 + 1) * a.D + sl) * n + tile_off;
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = threadIdx.x + i * NTT_THREADS;
+            const ulong2 yy = reinterpret_cast<const ulong2 *>(y0)[e];
+            const ulong2 b = reinterpret_cast<const ulong2 *>(e0)[e];
+            const ulong2 c = reinterpret_cast<const ulong2 *>(e1)[e];
+            const double yx = u52_to_double(yy.x), yz = u52_to_double(yy.y);
+            acc0[i].x = fp_mulmod_any(yx, u52_to_double(b.x), q, qinv);
+            acc0[i].y = fp_mulmod_any(yz, u52_to_double(b.y), q, qinv);
+            acc1[i].x = fp_mulmod_any(yx, u52_to_double(c.x), q, qinv);
+            acc1[i].y = fp_mulmod_any(yz, u52_to_double(c.y), q, qinv);
+        }
+    }
+#pragma unroll 1
+    for (int dj = jn; dj < NPARTS; dj = jn) {
+        jn = dj + 1 == own ? dj + 2 : dj + 1;  // next converted digit
+        {
+            u64 w[H - 1], wp[H - 1];
+            __syncthreads();  // twiddles staged (first digit) / previous digit's products finished reading LDS
+            TA::fetch(twa, twa_sh, g, w, wp);
+            radix_forward_fp<LOG_H>(x, w, wp, q, qinv);
+        }
+        u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
+        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w2, wp2);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
+        radix_forward_fp<LOG_H>(x, w2, wp2, q, qinv);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));  // |y| <= 0.51 q
+        if (jn < NPARTS) {  // next digit's inputs are requested while this digit's products stream
+            const u64 *src = dig0 + (size_t)jn * a.ext * n;
+#pragma unroll
+            for (int k = 0; k < H; ++k) x[k] = src[H * k];
+        }
+        __syncthreads();
+        const u64 *e0 = a.evk + (((size_t)dj * 2 + 0) * a.D + sl) * n + tile_off;
+        const u64 *e1 = a.evk + (((size_t)dj * 2 + 1) * a.D + sl) * n + tile_off;
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = threadIdx.x + i * NTT_THREADS;
+            const int gg = (2 * e) / R, xx = (2 * e) % R;
+            const ulong2 b = reinterpret_cast<const ulong2 *>(e0)[e];
+            const ulong2 c = reinterpret_cast<const ulong2 *>(e1)[e];
+            const double yx = bitsd(lds[TL::at(gg, xx)]), yz = bitsd(lds[TL::at(gg, xx + 1)]);
+            acc0[i].x += fp_mulmod_any(yx, u52_to_double(b.x), q, qinv);
+            acc0[i].y += fp_mulmod_any(yz, u52_to_double(b.y), q, qinv);
+            acc1[i].x += fp_mulmod_any(yx, u52_to_double(c.x), q, qinv);
+            acc1[i].y += fp_mulmod_any(yz, u52_to_double(c.y), q, qinv);
+        }
+    }
+    // |acc| <= (0.97 + 0.75 (NPARTS-1)) q < 2^53: exact integers
+    u64 *t0 = a.til + (((size_t)item * 2 + 0) * a.ext + sl) * n + tile_off;
+    u64 *t1 = a.til + (((size_t)item * 2 + 1) * a.ext + sl) * n + tile_off;
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+        const int e = threadIdx.x + i * NTT_THREADS;
+        ulong2 r0, r1v;
+        r0.x = fp_to_canonical(acc0[i].x, q, qinv);
+        r0.y = fp_to_canonical(acc0[i].y, q, qinv);
+        r1v.x = fp_to_canonical(acc1[i].x, q, qinv);
+        r1v.y = fp_to_canonical(acc1[i].y, q, qinv);
+        reinterpret_cast<ulong2 *>(t0)[e] = r0;
+        reinterpret_cast<ulong2 *>(t1)[e] = r1v;
+    }
+}
+
 // ---- 512-point rows (N = 2^17 = 256 x 512): three rounds of radix 8 ---------------------------------------
 // Position x = 64a + 8b + c of a row; a thread is (p, r) with p, r < 8 and holds 8 words per round:
 //   round A: (a,b,c) = (k,p,r)  stages 0-2  base_eff = base

@@ -455,6 +455,8 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
         MK_HIP(hipEventCreateWithFlags(&ev_b_, hipEventDisableTiming));
         MK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         MK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        for (auto &st : extra_lane_) MK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (auto &ev : ev_lane_) MK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     MK_HIP(hipMalloc(&d_limb_, D * sizeof(LimbConst)));
     MK_HIP(hipMemcpy(d_limb_, ps_.limb.data(), D * sizeof(LimbConst), hipMemcpyHostToDevice));
@@ -517,6 +519,10 @@ Engine::~Engine() {
     if (ev_b_) (void)hipEventDestroy(ev_b_);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
+    for (auto st : extra_lane_)
+        if (st) (void)hipStreamDestroy(st);
+    for (auto ev : ev_lane_)
+        if (ev) (void)hipEventDestroy(ev);
 }
 
 Lanes Engine::lanes() const {
@@ -1232,7 +1238,10 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
         // step time with the sum of rocprof kernel durations)
         static const bool one_lane = [] { const char *e = std::getenv("MKCKKS_SUM_ONE_LANE"); return e && std::atoi(e) == 1; }();
         const bool two = side_stream_ != nullptr && n_clients > 1 && !one_lane;
-        u64 *ws = workspace((size_t)n_clients * (w_til + w_conv) + (two ? 2 : 1) * w_lane);
+        // clients in flight at once, each on its own stream with its own {coef, dig, pc} arena
+        static const uint32_t lanes_env = [] { const char *e = std::getenv("MKCKKS_SUM_LANES"); return e ? (uint32_t)std::atoi(e) : 2u; }();
+        const uint32_t n_lanes = !two ? 1u : std::min<uint32_t>(std::min<uint32_t>(std::max(lanes_env, 2u), MAX_SUM_LANES), n_clients);
+        u64 *ws = workspace((size_t)n_clients * (w_til + w_conv) + (size_t)n_lanes * w_lane);
         u64 *til0 = ws, *conv0 = til0 + (size_t)n_clients * w_til, *lane0 = conv0 + (size_t)n_clients * w_conv;
         hipStream_t main = stream_;
         struct Restore {  // the per-client helpers launch on stream_; put it back on every exit path
@@ -1246,16 +1255,17 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
         // (15.7-15.9 k) or 2 (15.5 k) clients overlapped with the next group's key switching
         const uint32_t group = (two && group_env) ? group_env : n_clients;
         hipStream_t sum_stream = two ? sum_stream_ : main;
+        hipStream_t lane_stream[MAX_SUM_LANES] = {main, side_stream_, extra_lane_[0], extra_lane_[1]};
         if (two) {
             MK_HIP(hipEventRecord(ev_fork_, main));
-            MK_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
+            for (uint32_t l = 1; l < n_lanes; ++l) MK_HIP(hipStreamWaitEvent(lane_stream[l], ev_fork_, 0));
             MK_HIP(hipStreamWaitEvent(sum_stream_, ev_fork_, 0));
         }
         for (uint32_t c0 = 0; c0 < n_clients; c0 += group) {
             const uint32_t gcnt = std::min(group, n_clients - c0);
             for (uint32_t c = c0; c < c0 + gcnt; ++c) {
-                const uint32_t lane = two ? (c & 1) : 0;
-                stream_ = lane ? side_stream_ : main;  // the helpers below launch on stream_
+                const uint32_t lane = c % n_lanes;
+                stream_ = lane_stream[lane];  // the helpers below launch on stream_
                 u64 *coef = lane0 + (size_t)lane * w_lane, *dig = coef + w_coef, *pc = dig + w_dig;
                 u64 *til = til0 + (size_t)c * w_til, *conv = conv0 + (size_t)c * w_conv;
                 const u64 *ct = cts + ((size_t)c * n_ct + b0) * ct_words, *evk = evks + (size_t)c * evk_words;
@@ -1268,11 +1278,11 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
                 launch_conv_col(io, tabs_, moddown_conv(nl), lanes());
             }
             stream_ = main;
-            if (two) {  // the group's sum waits for both lanes; the lanes go on with the next group
-                MK_HIP(hipEventRecord(ev_a_, main));
-                MK_HIP(hipEventRecord(ev_b_, side_stream_));
-                MK_HIP(hipStreamWaitEvent(sum_stream_, ev_a_, 0));
-                MK_HIP(hipStreamWaitEvent(sum_stream_, ev_b_, 0));
+            if (two) {  // the group's sum waits for every lane; the lanes go on with the next group
+                for (uint32_t l = 0; l < n_lanes; ++l) {
+                    MK_HIP(hipEventRecord(ev_lane_[l], lane_stream[l]));
+                    MK_HIP(hipStreamWaitEvent(sum_stream_, ev_lane_[l], 0));
+                }
             }
             SumArgs a{conv0 + (size_t)c0 * w_conv, til0 + (size_t)c0 * w_til,
                       cts + ((size_t)c0 * n_ct + b0) * ct_words, out + (size_t)b0 * ct_words, pinv, pinv + nl,

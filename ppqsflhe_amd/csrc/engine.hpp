@@ -131,6 +131,9 @@ private:
     hipStream_t side_stream_ = nullptr;  // second lane for the fp64 instances of a pass
     hipStream_t sum_stream_ = nullptr;   // fused sum kernels of finished client groups (reencrypt_sum)
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_a_ = nullptr, ev_b_ = nullptr;
+    static constexpr int MAX_SUM_LANES = 4;  // client lanes of reencrypt_sum: main, side_stream_, extra_lane_[0..1]
+    hipStream_t extra_lane_[MAX_SUM_LANES - 2] = {nullptr, nullptr};
+    hipEvent_t ev_lane_[MAX_SUM_LANES] = {nullptr, nullptr, nullptr, nullptr};
     bool two_lanes_ = false;
     uint32_t *d_rot_ = nullptr;
     void *d_ksi_ = nullptr;

@@ -187,6 +187,36 @@ struct RowTwA {
     }
 };
 
+// Wave-local row tiles.  A row of R = H*H words is handled by H threads, i.e. a wavefront owns 64/H complete rows in
+// BOTH rounds (the exchange between the rounds stays inside a row).  When the copy-in / copy-out phases use the same
+// ownership (wave_pair below: one wave instruction = 1 KiB contiguous), no LDS word is ever touched by two waves and
+// the workgroup barriers become wave-level ordering points: a wave's own ds_write / ds_read execute in order.
+MK_D void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// i-th 16-byte access (pair of words, index into the tile's pairs) of this lane inside its wave's rows
+template <int LOG_H>
+MK_D int wave_pair(int i) {
+    constexpr int PER_WAVE = (64 >> LOG_H) * (1 << (2 * LOG_H)) / 2;
+    return (int)(threadIdx.x / 64) * PER_WAVE + (int)(threadIdx.x % 64) + 64 * i;
+}
+// round-A twiddles of this wave's rows only (same LDS layout as RowTwA::stage; RW = 64/H rows per wave)
+template <int LOG_H>
+MK_D void stage_twiddles_wave(u64 *ldsw, u64 *ldswp, const u64 *tw, const u64 *tw_sh, uint32_t base0) {
+    constexpr int H = 1 << LOG_H, S = 256 / H, RW = 64 / H;
+    const int wv = threadIdx.x / 64;
+    for (int e = threadIdx.x % 64; e < RW * (H - 1); e += 64) {
+        const int s = 31 - __clz(e / RW + 1);
+        const int off = e - RW * ((1 << s) - 1);
+        const uint32_t idx = ((base0 + (uint32_t)(RW * wv)) << s) + (uint32_t)off;
+        const int dst = S * ((1 << s) - 1) + ((RW * wv) << s) + off;
+        ldsw[dst] = tw[idx];
+        ldswp[dst] = tw_sh[idx];
+    }
+}
+
 // ---- kernels -----------------------------------------------------------------------
 
 // Forward column pass, everything after the H input words of this thread (rows j + H k, column c) are
@@ -604,12 +634,12 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
     const uint32_t base = r1 + row0 + g;
     const u64 pi = a.pinv[sl], pi_sh = a.pinv_sh[sl];
     const size_t tile_off = (size_t)row0 * R;
-    TA::stage(twa, twa_sh, tw, tw_sh, r1 + row0);
+    stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);
     u64 *dst = a.out + ((size_t)poly * a.nl + sl) * n + tile_off;
     ulong2 acc[PAIRS];
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i)
-        acc[i] = a.init_from_out ? reinterpret_cast<const ulong2 *>(dst)[threadIdx.x + i * NTT_THREADS] : ulong2{0, 0};
+        acc[i] = a.init_from_out ? reinterpret_cast<const ulong2 *>(dst)[wave_pair<LOG_H>(i)] : ulong2{0, 0};
     const u64 *src0 = a.conv + ((size_t)poly * a.nl + sl) * n + tile_off + (size_t)g * R + j;
     const size_t til_off = ((size_t)poly * a.ext + sl) * n + tile_off;
     const size_t ct_off = (size_t)(poly >> 1) * a.ct_stride + (size_t)sl * n + tile_off;
@@ -627,7 +657,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
         const uint32_t cb = has_b ? c + 1 : c;
         {
             u64 w[H - 1], wp[H - 1];
-            __syncthreads();  // twiddles staged (first pair) / previous pair's tail finished reading LDS
+            wave_lds_sync();  // twiddles staged (first pair) / previous pair's tail finished reading LDS
             TA::fetch(twa, twa_sh, g, w, wp);
             radix_forward_any<LOG_H, FP>(xa, w, wp, lc);
             radix_forward_any<LOG_H, FP>(xb, w, wp, lc);
@@ -639,7 +669,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
             lds[TL::at(g, j + H * k)] = xa[k];
             ldsb[TL::at(g, j + H * k)] = xb[k];
         }
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < H; ++k) {
             xa[k] = lds[TL::at(g, H * j + k)];
@@ -660,14 +690,14 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
 #pragma unroll
             for (int k = 0; k < H; ++k) xb[k] = nb[H * k];
         }
-        __syncthreads();
+        wave_lds_sync();
         const u64 *tqa = a.til + (size_t)c * a.til_cstride + til_off;
         const u64 *tqb = a.til + (size_t)cb * a.til_cstride + til_off;
         const u64 *c0a = a.cts + (size_t)c * a.ct_cstride + ct_off;
         const u64 *c0b = a.cts + (size_t)cb * a.ct_cstride + ct_off;
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
-            const int e = threadIdx.x + i * NTT_THREADS;
+            const int e = wave_pair<LOG_H>(i);
             const int gg = (2 * e) / R, xx = (2 * e) % R;
             const ulong2 ta = reinterpret_cast<const ulong2 *>(tqa)[e];
             const ulong2 tb = reinterpret_cast<const ulong2 *>(tqb)[e];
@@ -696,7 +726,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
         }
     }
 #pragma unroll
-    for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[threadIdx.x + i * NTT_THREADS] = acc[i];
+    for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[wave_pair<LOG_H>(i)] = acc[i];
 }
 
 // ModUp row pass + inner product with the eval key in ONE kernel, fp64 limbs only (EvalKeySwitchPrecomputeCore's
@@ -741,7 +771,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
     const uint32_t base = r1 + row0 + g;
     const size_t tile_off = (size_t)row0 * R;
     const double q = lc.qd, qinv = lc.qinv;
-    TA::stage(twa, twa_sh, tw, tw_sh, r1 + row0);  // round-A twiddles are the same for every digit
+    stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);  // round-A twiddles are the same for every digit
     int jn = own == 0 ? 1 : 0;  // first converted digit
     const u64 *dig0 = a.dig + ((size_t)item * NPARTS * a.ext + sl) * n + tile_off + (size_t)g * R + j;
     u64 x[H];
@@ -757,7 +787,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
         const u64 *e1 = a.evk + (((size_t)own * 2 + 1) * a.D + sl) * n + tile_off;
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
-            const int e = threadIdx.x + i * NTT_THREADS;
+            const int e = wave_pair<LOG_H>(i);
             const ulong2 yy = reinterpret_cast<const ulong2 *>(y0)[e];
             const ulong2 b = reinterpret_cast<const ulong2 *>(e0)[e];
             const ulong2 c = reinterpret_cast<const ulong2 *>(e1)[e];
@@ -773,7 +803,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
         jn = dj + 1 == own ? dj + 2 : dj + 1;  // next converted digit
         {
             u64 w[H - 1], wp[H - 1];
-            __syncthreads();  // twiddles staged (first digit) / previous digit's products finished reading LDS
+            wave_lds_sync();  // twiddles staged (first digit) / previous digit's products finished reading LDS
             TA::fetch(twa, twa_sh, g, w, wp);
             radix_forward_fp<LOG_H>(x, w, wp, q, qinv);
         }
@@ -781,7 +811,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
         load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w2, wp2);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
         radix_forward_fp<LOG_H>(x, w2, wp2, q, qinv);
@@ -792,12 +822,12 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
 #pragma unroll
             for (int k = 0; k < H; ++k) x[k] = src[H * k];
         }
-        __syncthreads();
+        wave_lds_sync();
         const u64 *e0 = a.evk + (((size_t)dj * 2 + 0) * a.D + sl) * n + tile_off;
         const u64 *e1 = a.evk + (((size_t)dj * 2 + 1) * a.D + sl) * n + tile_off;
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
-            const int e = threadIdx.x + i * NTT_THREADS;
+            const int e = wave_pair<LOG_H>(i);
             const int gg = (2 * e) / R, xx = (2 * e) % R;
             const ulong2 b = reinterpret_cast<const ulong2 *>(e0)[e];
             const ulong2 c = reinterpret_cast<const ulong2 *>(e1)[e];
@@ -813,7 +843,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
     u64 *t1 = a.til + (((size_t)item * 2 + 1) * a.ext + sl) * n + tile_off;
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
-        const int e = threadIdx.x + i * NTT_THREADS;
+        const int e = wave_pair<LOG_H>(i);
         ulong2 r0, r1v;
         r0.x = fp_to_canonical(acc0[i].x, q, qinv);
         r0.y = fp_to_canonical(acc0[i].y, q, qinv);

@@ -389,7 +389,7 @@ template <int LOG_H, bool INV, bool FP>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T, TailArgs tail) {
     using TL = RowTile<LOG_H>;
     using TA = RowTwA<LOG_H>;
-    constexpr int H = TL::H, S = TL::S, R = TL::R;
+    constexpr int H = TL::H, S = TL::S, R = TL::R, PAIRS = S * R / 2 / NTT_THREADS;
     __shared__ u64 lds[TL::WORDS + 2 * TA::WORDS];
     u64 *twa = lds + TL::WORDS, *twa_sh = twa + TA::WORDS;
     // 1-D grid over (limb slot, row tile, polynomial).  All polynomials of one (slot, tile) read the same
@@ -422,24 +422,25 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
     if (!INV) {
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = src[(size_t)g * R + j + H * k];
-        TA::stage(twa, twa_sh, tw, tw_sh, r1 + row0);
-        __syncthreads();
+        stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);
+        wave_lds_sync();
         TA::fetch(twa, twa_sh, g, w, wp);
         radix_forward_any<LOG_H, FP>(x, w, wp, lc);
         u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
         load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w2, wp2);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
         radix_forward_any<LOG_H, FP>(x, w2, wp2, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k)  // canonical u64, own words only
             lds[TL::at(g, H * j + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
-        __syncthreads();
+        wave_lds_sync();
         if (!tail.enabled) {
-            for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
+            for (int i = 0; i < PAIRS; ++i) {
+                const int e = wave_pair<LOG_H>(i);
                 const int gg = (2 * e) / R, xx = (2 * e) % R;
                 ulong2 v;
                 v.x = lds[TL::at(gg, xx)];
@@ -452,7 +453,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
             const u64 *c0 = (tail.add && (poly & 1) == 0)
                                 ? tail.add + (size_t)(poly >> 1) * tail.add_stride + (size_t)sl * n + (size_t)row0 * R
                                 : nullptr;
-            for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
+            for (int i = 0; i < PAIRS; ++i) {
+                const int e = wave_pair<LOG_H>(i);
                 const int gg = (2 * e) / R, xx = (2 * e) % R;
                 const ulong2 t = reinterpret_cast<const ulong2 *>(tq)[e];
                 ulong2 v;
@@ -473,14 +475,15 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         }
     } else {
         load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);  // first: in flight while the tile is staged
-        for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
+        for (int i = 0; i < PAIRS; ++i) {
+                const int e = wave_pair<LOG_H>(i);
             const int gg = (2 * e) / R, xx = (2 * e) % R;
             const ulong2 v = reinterpret_cast<const ulong2 *>(src)[e];
             lds[TL::at(gg, xx)] = v.x;
             lds[TL::at(gg, xx + 1)] = v.y;
         }
-        TA::stage(twa, twa_sh, tw, tw_sh, r1 + row0);  // for the second (broadcast) round
-        __syncthreads();
+        stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);  // for the second (broadcast) round
+        wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
         if (FP) {  // canonical input -> doubles
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = x[k];
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, j + H * k)];
         TA::fetch(twa, twa_sh, g, w, wp);
@@ -545,12 +548,12 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, 
     const uint32_t base = r1 + row0 + g;
     const u64 pi = a.pinv[sl], pi_sh = a.pinv_sh[sl];
     const size_t tile_off = (size_t)row0 * R;
-    TA::stage(twa, twa_sh, tw, tw_sh, r1 + row0);  // round-A twiddles are the same for every client
+    stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);  // round-A twiddles are the same for every client
     u64 *dst = a.out + ((size_t)poly * a.nl + sl) * n + tile_off;
     ulong2 acc[PAIRS];
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i)
-        acc[i] = a.init_from_out ? reinterpret_cast<const ulong2 *>(dst)[threadIdx.x + i * NTT_THREADS] : ulong2{0, 0};
+        acc[i] = a.init_from_out ? reinterpret_cast<const ulong2 *>(dst)[wave_pair<LOG_H>(i)] : ulong2{0, 0};
     // software pipeline over clients: the H input words of client c+1 are requested while client c's tail streams
     // (x[] is dead by then), so their latency is off the critical path
     const u64 *src0 = a.conv + ((size_t)poly * a.nl + sl) * n + tile_off + (size_t)g * R + j;
@@ -559,12 +562,12 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, 
     for (int k = 0; k < H; ++k) x[k] = src0[H * k];
     for (uint32_t c = 0; c < a.n_clients; ++c) {
         u64 w[H - 1], wp[H - 1];
-        __syncthreads();  // twiddles staged (first client) / previous client's copy-out finished reading LDS
+        wave_lds_sync();  // twiddles staged (first client) / previous client's copy-out finished reading LDS
         TA::fetch(twa, twa_sh, g, w, wp);
         radix_forward_any<LOG_H, FP>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
         load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);
@@ -577,14 +580,14 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, 
 #pragma unroll
             for (int k = 0; k < H; ++k) x[k] = nxt[H * k];
         }
-        __syncthreads();
+        wave_lds_sync();
         const u64 *tq = a.til + (size_t)c * a.til_cstride + ((size_t)poly * a.ext + sl) * n + tile_off;
         const u64 *c0 = (poly & 1) == 0
                             ? a.cts + (size_t)c * a.ct_cstride + (size_t)(poly >> 1) * a.ct_stride + (size_t)sl * n + tile_off
                             : nullptr;
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
-            const int e = threadIdx.x + i * NTT_THREADS;
+            const int e = wave_pair<LOG_H>(i);
             const int gg = (2 * e) / R, xx = (2 * e) % R;
             const ulong2 t = reinterpret_cast<const ulong2 *>(tq)[e];
             ulong2 v;
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, 
         }
     }
 #pragma unroll
-    for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[threadIdx.x + i * NTT_THREADS] = acc[i];
+    for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[wave_pair<LOG_H>(i)] = acc[i];
 }
 
 // Same pass with TWO clients in flight per workgroup iteration: both clients' tiles go through the rounds together,

@@ -1141,7 +1141,8 @@ static void launch_row_inner_fp_n(const InnerArgs &a, const NttTables &T, uint32
 void Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u64 *coef, u64 *dig, u64 *til,
                               uint32_t cnt, uint32_t nl) {
     const uint32_t n = ps_.n, ext = nl + ps_.K, nparts = ps_.num_parts(nl), D = ps_.D;
-    static const bool fuse_env = [] { const char *e = std::getenv("MKCKKS_FUSE_INNER"); return !e || std::atoi(e) != 0; }();
+    const char *fe = std::getenv("MKCKKS_FUSE_INNER");  // read per call: the tests run both paths in one process
+    const bool fuse_env = !fe || std::atoi(fe) != 0;
     const int row_h = fast_log_h(tabs_.log_r2, 1u << tabs_.log_r1);
     unsigned long long fp_mask = 0, all_mask = ext >= 64 ? ~0ull : ((1ull << ext) - 1);
     for (uint32_t i = 0; i < nl; ++i)
@@ -1196,7 +1197,8 @@ static void launch_row_tail_sum(SumArgs a, const NttTables &T, uint32_t L, hipSt
     static const int waves = [] { const char *e = std::getenv("MKCKKS_SUM_WAVES"); return e ? std::atoi(e) : 2; }();  // 2: no spills (212 VGPRs); measured equal to 3, faster than 4
     const dim3 gi(tiles * ai.nsel * a.n_polys), gf(tiles * af.nsel * a.n_polys);
     // two clients per workgroup iteration (shared twiddle fetches, two dependency chains): the default
-    static const bool pair = [] { const char *e = std::getenv("MKCKKS_SUM_PAIR"); return !e || std::atoi(e) != 0; }();
+    const char *pe = std::getenv("MKCKKS_SUM_PAIR");  // read per call: the tests run both kernels in one process
+    const bool pair = !pe || std::atoi(pe) != 0;
     if (pair && LOG_H == 4) {
         if (ai.nsel) k_row_tail_sum2<LOG_H, false><<<gi, NTT_THREADS, 0, s>>>(ai, T);
         if (af.nsel) k_row_tail_sum2<LOG_H, true><<<gf, NTT_THREADS, 0, s>>>(af, T);

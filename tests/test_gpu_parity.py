@@ -375,6 +375,32 @@ def test_reencrypt_sum(ctxs, name, nl, C, B):
         assert np.array_equal(got[b], acc)
 
 
+@pytest.mark.parametrize("env", [{"MKCKKS_FUSE_INNER": "0"}, {"MKCKKS_SUM_PAIR": "0"},
+                                 {"MKCKKS_FUSE_INNER": "0", "MKCKKS_SUM_PAIR": "0"}])
+def test_unfused_kernel_paths_stay_bit_exact(ctxs, monkeypatch, env):
+    """The separate row pass + inner product and the one-client-per-iteration sum kernel remain in the library (other
+    ring sizes, switches for A/B measurements): same bits as the fused default and as the oracle at N = 2^16."""
+    g, o = ctxs("c3")
+    nl, C, B = 12, 3, 1
+    rng = np.random.default_rng(77)
+    cts = np.stack([rand_ct(rng, g, nl, B) for _ in range(C)])
+    evks = np.stack([rand_polys(rng, g, list(range(g.D)) * (2 * g.beta), 1).reshape(g.beta, 2, g.D, g.N)
+                     for _ in range(C)])
+    d_cts, d_evks = g.to_device(cts), g.to_device(evks)
+    d_ref = g.empty((B, 2, nl, g.N))
+    g.reencrypt_sum(d_cts, d_evks, d_ref, C, B, nl)
+    want = d_ref.to_host()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    d_out = g.empty((B, 2, nl, g.N))
+    g.reencrypt_sum(d_cts, d_evks, d_out, C, B, nl)
+    got = d_out.to_host()
+    assert np.array_equal(got, want)
+    d_one = g.empty((B, 2, nl, g.N))
+    g.reencrypt(g.to_device(cts[0]), g.to_device(evks[0]), d_one, B, nl)
+    assert np.array_equal(d_one.to_host()[0], o.reencrypt(cts[0, 0], evks[0]))
+
+
 def test_device_samplers(ctxs):
     """Philox samplers in HBM: distributional checks (OpenFHE's PRNG stream is not reproducible), determinism per
     (seed, stream), independence across streams, exact range of the uniform limbs."""

@@ -408,6 +408,27 @@ __global__ void k_fma(Opnd x, Opnd y, Opnd z, Opnd w, const u64 *wc, int negate_
 // =====================================================================================
 
 static int fast_log_h(uint32_t log_r, uint32_t other_extent);
+
+// packed round-B twiddle table of the two-round row kernels (layout: NttTables::twb)
+__global__ void k_pack_rowb(const u64 *tw, const u64 *tw_sh, u64 *out, uint32_t log_n, uint32_t log_r1, uint32_t log_h,
+                            uint32_t limbs) {
+    const uint32_t n = 1u << log_n, r1 = 1u << log_r1, H = 1u << log_h;
+    const size_t total = (size_t)limbs * n, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one (w, wp) pair each
+    if (t >= total) return;
+    const uint32_t j = (uint32_t)(t % H), i = (uint32_t)((t / H) % H), row = (uint32_t)((t / ((size_t)H * H)) % r1);
+    const uint32_t limb = (uint32_t)(t / n);
+    u64 w = 0, wp = 0;
+    if (i < H - 1) {
+        const uint32_t s = 31u - (uint32_t)__clz(i + 1), gq = i - ((1u << s) - 1);
+        const uint32_t idx = ((((r1 + row) << log_h) + j) << s) + gq;
+        w = tw[(size_t)limb * n + idx];
+        wp = tw_sh[(size_t)limb * n + idx];
+    }
+    out[2 * t] = w;
+    out[2 * t + 1] = wp;
+}
+
+
 static int fast_row(uint32_t log_r2, uint32_t rows);
 
 static dim3 ew_grid(uint32_t n, uint32_t slots, uint32_t items) {
@@ -500,6 +521,19 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
         MK_HIP(hipMemcpy(d_rot_, rot.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice));
         MK_HIP(hipMemcpy(d_ksi_, ksi.data(), (M + 1) * sizeof(double2), hipMemcpyHostToDevice));
     }
+    tabs_.twb = tabs_.itwb = nullptr;
+    if (const int lh = fast_log_h(tabs_.log_r2, 1u << tabs_.log_r1)) {  // two-round row kernels: packed round-B tables
+        MK_HIP(hipMalloc(&d_twb_, 2 * tbytes));
+        MK_HIP(hipMalloc(&d_itwb_, 2 * tbytes));
+        const size_t total = (size_t)D * n;
+        const dim3 grid((unsigned)((total + 255) / 256));
+        k_pack_rowb<<<grid, 256>>>(d_tw_, d_tw_sh_, d_twb_, ps_.log_n, tabs_.log_r1, (uint32_t)lh, D);
+        k_pack_rowb<<<grid, 256>>>(d_itw_, d_itw_sh_, d_itwb_, ps_.log_n, tabs_.log_r1, (uint32_t)lh, D);
+        MK_HIP(hipGetLastError());
+        MK_HIP(hipDeviceSynchronize());
+        tabs_.twb = d_twb_;
+        tabs_.itwb = d_itwb_;
+    }
     tabs_.limb = d_limb_;
     tabs_.tw = d_tw_; tabs_.tw_sh = d_tw_sh_; tabs_.itw = d_itw_; tabs_.itw_sh = d_itw_sh_;
     tabs_.L = ps_.L;
@@ -510,6 +544,7 @@ Engine::~Engine() {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     for (void *p : {(void *)d_limb_, (void *)d_tw_, (void *)d_tw_sh_, (void *)d_itw_, (void *)d_itw_sh_, (void *)ws_,
+                    (void *)d_twb_, (void *)d_itwb_,
                     (void *)d_rot_, (void *)d_ksi_})
         if (p) (void)hipFree(p);
     for (void *p : owned_) (void)hipFree(p);

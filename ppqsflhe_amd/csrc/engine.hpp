@@ -127,6 +127,7 @@ private:
     NttTables tabs_{};
     LimbConst *d_limb_ = nullptr;
     u64 *d_tw_ = nullptr, *d_tw_sh_ = nullptr, *d_itw_ = nullptr, *d_itw_sh_ = nullptr;
+    u64 *d_twb_ = nullptr, *d_itwb_ = nullptr;  // packed round-B tables of the row kernels (NttTables::twb)
     std::vector<uint8_t> fp_of_;  // per limb id: 1 = fp64 kernel instance
     hipStream_t side_stream_ = nullptr;  // second lane for the fp64 instances of a pass
     hipStream_t sum_stream_ = nullptr;   // fused sum kernels of finished client groups (reencrypt_sum)

@@ -33,6 +33,10 @@ struct NttTables {
     const LimbConst *limb;  // [D]
     const u64 *tw, *tw_sh;  // [D][N] forward psi^bitrev(k) + Shoup companions
     const u64 *itw, *itw_sh;
+    // round-B twiddles of the two-round row kernels, re-laid out so that one wave instruction reads contiguous memory:
+    // [D][r1 rows][H chunks][H threads] pairs (w, companion); chunk i < H-1 is twiddle i of the round, chunk H-1 pads.
+    // (From the plain tables a thread's 15 pairs sit up to 64 B apart per lane: 32 cache lines per wave instruction.)
+    const u64 *twb, *itwb;
     uint32_t log_n, log_r1, log_r2;
     uint32_t L;  // #Q limbs at full level (P limbs start at id L)
     uint32_t has_fp;  // some limbs run on the fp64 kernel instances (host launches both instances then)

@@ -37,6 +37,21 @@ MK_D void load_round_twiddles(const u64 *__restrict__ tw, const u64 *__restrict_
     }
 }
 
+// round-B twiddles of a row kernel thread (row of the limb, position j in the row) from the packed table
+// NttTables::twb / itwb: chunk i of the row is H consecutive 16-byte pairs, one per thread
+template <int LOG_H>
+MK_D void load_rowb_twiddles(const u64 *__restrict__ twb_limb, uint32_t row, int j, u64 (&w)[(1 << LOG_H) - 1],
+                             u64 (&wp)[(1 << LOG_H) - 1]) {
+    constexpr int H = 1 << LOG_H;
+    const ulong2 *p = reinterpret_cast<const ulong2 *>(twb_limb) + (size_t)row * H * H + j;
+#pragma unroll
+    for (int i = 0; i < H - 1; ++i) {
+        const ulong2 t = p[i * H];
+        w[i] = t.x;
+        wp[i] = t.y;
+    }
+}
+
 // log2(H) forward stages on H registers.  Inputs < 8q, outputs < 8q: even stages bring x back below 4q
 // before the butterfly (outputs < 6q), odd stages skip the correction (outputs < 8q) -- half the
 // conditional subtractions of the classic Harvey schedule; 8q < 2^63 since q < 2^60.
@@ -417,7 +432,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
     u64 *dst = io.out + (size_t)poly * io.out_stride + (size_t)(io.out_slot0 + sl) * n + (size_t)row0 * R;
     const u64 *tw = (INV ? T.itw : T.tw) + (size_t)id * n;
     const u64 *tw_sh = (INV ? T.itw_sh : T.tw_sh) + (size_t)id * n;
-    const uint32_t base = r1 + row0 + g;
+    const u64 *twb = (INV ? T.itwb : T.twb) + (size_t)id * 2 * n;
     u64 x[H], w[H - 1], wp[H - 1];
     if (!INV) {
 #pragma unroll
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         TA::fetch(twa, twa_sh, g, w, wp);
         radix_forward_any<LOG_H, FP>(x, w, wp, lc);
         u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
-        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w2, wp2);
+        load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
         wave_lds_sync();
@@ -474,7 +489,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
             }
         }
     } else {
-        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);  // first: in flight while the tile is staged
+        load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w, wp);  // first: in flight while the tile is staged
         for (int i = 0; i < PAIRS; ++i) {
                 const int e = wave_pair<LOG_H>(i);
             const int gg = (2 * e) / R, xx = (2 * e) % R;
@@ -545,7 +560,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, 
     const uint32_t row0 = (grp % tiles) * S;
     const int g = threadIdx.x / H, j = threadIdx.x % H;
     const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
-    const uint32_t base = r1 + row0 + g;
+    const u64 *twb = T.twb + (size_t)sl * 2 * n;
     const u64 pi = a.pinv[sl], pi_sh = a.pinv_sh[sl];
     const size_t tile_off = (size_t)row0 * R;
     stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);  // round-A twiddles are the same for every client
@@ -570,7 +585,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, 
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
-        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w, wp);
+        load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w, wp);
         radix_forward_any<LOG_H, FP>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k)
@@ -634,7 +649,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
     const uint32_t row0 = (grp % tiles) * S;
     const int g = threadIdx.x / H, j = threadIdx.x % H;
     const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
-    const uint32_t base = r1 + row0 + g;
+    const u64 *twb = T.twb + (size_t)sl * 2 * n;
     const u64 pi = a.pinv[sl], pi_sh = a.pinv_sh[sl];
     const size_t tile_off = (size_t)row0 * R;
     stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);
@@ -666,7 +681,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
             radix_forward_any<LOG_H, FP>(xb, w, wp, lc);
         }
         u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
-        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w2, wp2);
+        load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
 #pragma unroll
         for (int k = 0; k < H; ++k) {
             lds[TL::at(g, j + H * k)] = xa[k];
@@ -771,7 +786,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
     const uint32_t row0 = (grp % tiles) * S;
     const int g = threadIdx.x / H, j = threadIdx.x % H;
     const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
-    const uint32_t base = r1 + row0 + g;
+    const u64 *twb = T.twb + (size_t)sl * 2 * n;
     const size_t tile_off = (size_t)row0 * R;
     const double q = lc.qd, qinv = lc.qinv;
     stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);  // round-A twiddles are the same for every digit
@@ -811,7 +826,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
             radix_forward_fp<LOG_H>(x, w, wp, q, qinv);
         }
         u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
-        load_round_twiddles<LOG_H>(tw, tw_sh, base * H + j, w2, wp2);
+        load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
         wave_lds_sync();

@@ -163,7 +163,7 @@ def main():
     # optional extra streams: memory-bound kernels (inner product, sums) of one client's batch overlap the
     # multiply-bound NTT kernels of another's; every stream has its own context (tables + workspace arena)
     side = []
-    for _ in range(max(0, args.streams - 1)):
+    for _ in range(max(0, args.streams - 1) if args.mode == "accumulate" else 0):
         st = torch.cuda.Stream(device=dev)
         c2 = Context(args.log_n, args.depth, args.scaling_bits, 60, dnum=args.dnum, device=local_rank)
         c2.set_stream(st.cuda_stream)

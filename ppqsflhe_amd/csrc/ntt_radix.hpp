@@ -22,6 +22,49 @@
 
 namespace mk {
 
+// streaming (read-once / write-once) accesses: non-temporal (MK_NT in modarith.hpp: 1 = fused row kernels, 2 = every
+// transform pass; data re-read from L2 by other workgroups -- twiddles, eval-key tiles, conversion sources -- stay default)
+MK_D u64 ld_stream(const u64 *p) { return MK_NT ? __builtin_nontemporal_load(p) : *p; }
+MK_D ulong2 ld_stream2(const ulong2 *p) {
+    if (MK_NT) {
+        ulong2 v;
+        v.x = __builtin_nontemporal_load(&p->x);
+        v.y = __builtin_nontemporal_load(&p->y);
+        return v;
+    }
+    return *p;
+}
+MK_D u64 ld_pass(const u64 *p) { return MK_NT >= 2 ? __builtin_nontemporal_load(p) : *p; }
+MK_D void st_pass(u64 *p, u64 v) {
+    if (MK_NT >= 2) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+MK_D ulong2 ld_pass2(const ulong2 *p) {
+    if (MK_NT >= 2) {
+        ulong2 v;
+        v.x = __builtin_nontemporal_load(&p->x);
+        v.y = __builtin_nontemporal_load(&p->y);
+        return v;
+    }
+    return *p;
+}
+MK_D void st_pass2(ulong2 *p, ulong2 v) {
+    if (MK_NT >= 2) {
+        __builtin_nontemporal_store(v.x, &p->x);
+        __builtin_nontemporal_store(v.y, &p->y);
+    } else {
+        *p = v;
+    }
+}
+MK_D void st_stream2(ulong2 *p, ulong2 v) {
+    if (MK_NT) {
+        __builtin_nontemporal_store(v.x, &p->x);
+        __builtin_nontemporal_store(v.y, &p->y);
+    } else {
+        *p = v;
+    }
+}
+
 // twiddles of one round: w[(1<<s) - 1 + g] = table[(base_eff << s) + g]
 template <int LOG_H>
 MK_D void load_round_twiddles(const u64 *__restrict__ tw, const u64 *__restrict__ tw_sh, uint32_t base_eff,
@@ -253,7 +296,7 @@ MK_D void col_forward_finish(u64 (&x)[1 << LOG_H], u64 *lds, const u64 *tw, cons
     for (int k = 0; k < H; ++k) x[k] = lds[TL::at(j, k, c)];  // row H j + k
     radix_forward_any<LOG_H, FP>(x, w2, wp2, lc);
 #pragma unroll
-    for (int k = 0; k < H; ++k) dst_col[(size_t)(H * j + k) * r2] = x[k];  // lazy u64, or doubles on an fp limb
+    for (int k = 0; k < H; ++k) st_pass(dst_col + (size_t)(H * j + k) * r2, x[k]);  // lazy u64, or doubles on an fp limb
 }
 
 // Column pass over R1 = H*H rows: one workgroup = S = 256/H adjacent columns.  Global accesses are
@@ -278,7 +321,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
     u64 x[H];
     if (!INV) {
 #pragma unroll
-        for (int k = 0; k < H; ++k) x[k] = src[(size_t)(j + H * k) * r2];
+        for (int k = 0; k < H; ++k) x[k] = ld_pass(src + (size_t)(j + H * k) * r2);
         if (FP) {  // canonical residues -> doubles (exact, q < 2^51)
 #pragma unroll
             for (int k = 0; k < H; ++k) x[k] = dbits((double)x[k]);
@@ -287,7 +330,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
     } else {
         u64 w[H - 1], wp[H - 1];
 #pragma unroll
-        for (int k = 0; k < H; ++k) x[k] = src[(size_t)(H * j + k) * r2];  // from the row pass: doubles on an fp limb
+        for (int k = 0; k < H; ++k) x[k] = ld_pass(src + (size_t)(H * j + k) * r2);  // from the row pass: doubles on an fp limb
         load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w, wp);
         radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
 #pragma unroll
@@ -304,7 +347,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
         for (int k = 0; k < H; ++k) {
             const u64 v = FP ? fp_to_canonical(fp_mulmod(bitsd(x[k]), bitsd(sc), bitsd(sc_sh), lc.qd), lc.qd, lc.qinv)
                                 : shoup_mul(x[k], sc, sc_sh, lc.q);
-            dst[(size_t)(j + H * k) * r2] = pack ? pack30(v) : v;  // packed halves feed k_conv_col directly
+            st_pass(dst + (size_t)(j + H * k) * r2, pack ? pack30(v) : v);  // packed halves feed k_conv_col directly
         }
     }
 }
@@ -436,7 +479,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
     u64 x[H], w[H - 1], wp[H - 1];
     if (!INV) {
 #pragma unroll
-        for (int k = 0; k < H; ++k) x[k] = src[(size_t)g * R + j + H * k];
+        for (int k = 0; k < H; ++k) x[k] = ld_pass(src + (size_t)g * R + j + H * k);
         stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);
         wave_lds_sync();
         TA::fetch(twa, twa_sh, g, w, wp);
@@ -460,7 +503,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
                 ulong2 v;
                 v.x = lds[TL::at(gg, xx)];
                 v.y = lds[TL::at(gg, xx + 1)];
-                reinterpret_cast<ulong2 *>(dst)[e] = v;
+                st_pass2(reinterpret_cast<ulong2 *>(dst) + e, v);
             }
         } else {
             const u64 pi = tail.pinv[sl], pi_sh = tail.pinv_sh[sl];
@@ -471,7 +514,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
             for (int i = 0; i < PAIRS; ++i) {
                 const int e = wave_pair<LOG_H>(i);
                 const int gg = (2 * e) / R, xx = (2 * e) % R;
-                const ulong2 t = reinterpret_cast<const ulong2 *>(tq)[e];
+                const ulong2 t = ld_pass2(reinterpret_cast<const ulong2 *>(tq) + e);
                 ulong2 v;
                 v.x = shoup_mul(sub_mod(t.x, lds[TL::at(gg, xx)], lc.q), pi, pi_sh, lc.q);
                 v.y = shoup_mul(sub_mod(t.y, lds[TL::at(gg, xx + 1)], lc.q), pi, pi_sh, lc.q);
@@ -485,7 +528,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
                     v.x = add_mod(v.x, a.x, lc.q);
                     v.y = add_mod(v.y, a.y, lc.q);
                 }
-                reinterpret_cast<ulong2 *>(dst)[e] = v;
+                st_pass2(reinterpret_cast<ulong2 *>(dst) + e, v);
             }
         }
     } else {
@@ -493,7 +536,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         for (int i = 0; i < PAIRS; ++i) {
                 const int e = wave_pair<LOG_H>(i);
             const int gg = (2 * e) / R, xx = (2 * e) % R;
-            const ulong2 v = reinterpret_cast<const ulong2 *>(src)[e];
+            const ulong2 v = ld_pass2(reinterpret_cast<const ulong2 *>(src) + e);
             lds[TL::at(gg, xx)] = v.x;
             lds[TL::at(gg, xx + 1)] = v.y;
         }
@@ -514,7 +557,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         TA::fetch(twa, twa_sh, g, w, wp);
         radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
 #pragma unroll
-        for (int k = 0; k < H; ++k) dst[(size_t)g * R + j + H * k] = x[k];  // lazy [0,2q) (doubles on an fp limb): the column pass scales
+        for (int k = 0; k < H; ++k) st_pass(dst + (size_t)g * R + j + H * k, x[k]);  // lazy [0,2q) (doubles on an fp limb): the column pass scales
     }
 }
 
@@ -666,9 +709,9 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
     {
         const u64 *pb = src0 + (size_t)(a.n_clients > 1 ? 1 : 0) * a.conv_cstride;
 #pragma unroll
-        for (int k = 0; k < H; ++k) xa[k] = src0[H * k];
+        for (int k = 0; k < H; ++k) xa[k] = ld_stream(src0 + H * k);
 #pragma unroll
-        for (int k = 0; k < H; ++k) xb[k] = pb[H * k];
+        for (int k = 0; k < H; ++k) xb[k] = ld_stream(pb + H * k);
     }
     for (uint32_t c = 0; c < a.n_clients; c += 2) {
         const bool has_b = c + 1 < a.n_clients;  // workgroup-uniform
@@ -704,9 +747,9 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
             const u64 *na = src0 + (size_t)(c + 2) * a.conv_cstride;
             const u64 *nb = src0 + (size_t)(c + 3 < a.n_clients ? c + 3 : c + 2) * a.conv_cstride;
 #pragma unroll
-            for (int k = 0; k < H; ++k) xa[k] = na[H * k];
+            for (int k = 0; k < H; ++k) xa[k] = ld_stream(na + H * k);
 #pragma unroll
-            for (int k = 0; k < H; ++k) xb[k] = nb[H * k];
+            for (int k = 0; k < H; ++k) xb[k] = ld_stream(nb + H * k);
         }
         wave_lds_sync();
         const u64 *tqa = a.til + (size_t)c * a.til_cstride + til_off;
@@ -717,16 +760,16 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
         for (int i = 0; i < PAIRS; ++i) {
             const int e = wave_pair<LOG_H>(i);
             const int gg = (2 * e) / R, xx = (2 * e) % R;
-            const ulong2 ta = reinterpret_cast<const ulong2 *>(tqa)[e];
-            const ulong2 tb = reinterpret_cast<const ulong2 *>(tqb)[e];
+            const ulong2 ta = ld_stream2(reinterpret_cast<const ulong2 *>(tqa) + e);
+            const ulong2 tb = ld_stream2(reinterpret_cast<const ulong2 *>(tqb) + e);
             ulong2 va, vb;
             va.x = shoup_mul(sub_mod(ta.x, lds[TL::at(gg, xx)], lc.q), pi, pi_sh, lc.q);
             va.y = shoup_mul(sub_mod(ta.y, lds[TL::at(gg, xx + 1)], lc.q), pi, pi_sh, lc.q);
             vb.x = shoup_mul(sub_mod(tb.x, ldsb[TL::at(gg, xx)], lc.q), pi, pi_sh, lc.q);
             vb.y = shoup_mul(sub_mod(tb.y, ldsb[TL::at(gg, xx + 1)], lc.q), pi, pi_sh, lc.q);
             if (with_c0) {
-                const ulong2 za = reinterpret_cast<const ulong2 *>(c0a)[e];
-                const ulong2 zb = reinterpret_cast<const ulong2 *>(c0b)[e];
+                const ulong2 za = ld_stream2(reinterpret_cast<const ulong2 *>(c0a) + e);
+                const ulong2 zb = ld_stream2(reinterpret_cast<const ulong2 *>(c0b) + e);
                 va.x = add_mod(va.x, za.x, lc.q);
                 va.y = add_mod(va.y, za.y, lc.q);
                 vb.x = add_mod(vb.x, zb.x, lc.q);
@@ -796,7 +839,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
     if (jn < NPARTS) {
         const u64 *src = dig0 + (size_t)jn * a.ext * n;
 #pragma unroll
-        for (int k = 0; k < H; ++k) x[k] = src[H * k];
+        for (int k = 0; k < H; ++k) x[k] = ld_stream(src + H * k);
     }
     double2 acc0[PAIRS], acc1[PAIRS];
     {   // the digit that owns this limb: c1 itself, already in EVALUATION format
@@ -806,7 +849,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
             const int e = wave_pair<LOG_H>(i);
-            const ulong2 yy = reinterpret_cast<const ulong2 *>(y0)[e];
+            const ulong2 yy = ld_stream2(reinterpret_cast<const ulong2 *>(y0) + e);
             const ulong2 b = reinterpret_cast<const ulong2 *>(e0)[e];
             const ulong2 c = reinterpret_cast<const ulong2 *>(e1)[e];
             const double yx = u52_to_double(yy.x), yz = u52_to_double(yy.y);
@@ -838,7 +881,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
         if (jn < NPARTS) {  // next digit's inputs are requested while this digit's products stream
             const u64 *src = dig0 + (size_t)jn * a.ext * n;
 #pragma unroll
-            for (int k = 0; k < H; ++k) x[k] = src[H * k];
+            for (int k = 0; k < H; ++k) x[k] = ld_stream(src + H * k);
         }
         wave_lds_sync();
         const u64 *e0 = a.evk + (((size_t)dj * 2 + 0) * a.D + sl) * n + tile_off;
@@ -867,8 +910,8 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
         r0.y = fp_to_canonical(acc0[i].y, q, qinv);
         r1v.x = fp_to_canonical(acc1[i].x, q, qinv);
         r1v.y = fp_to_canonical(acc1[i].y, q, qinv);
-        reinterpret_cast<ulong2 *>(t0)[e] = r0;
-        reinterpret_cast<ulong2 *>(t1)[e] = r1v;
+        st_stream2(reinterpret_cast<ulong2 *>(t0) + e, r0);
+        st_stream2(reinterpret_cast<ulong2 *>(t1) + e, r1v);
     }
 }
 

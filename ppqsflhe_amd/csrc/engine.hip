@@ -768,8 +768,8 @@ static void launch_col(const NttIo &io0, const NttTables &T, uint32_t n_polys, c
 }
 
 static bool row_tail_supported(const NttTables &T) { return fast_row(T.log_r2, 1u << T.log_r1) != 0; }
-// the fused n-client sum kernel exists for the two-round row kernels only
-static bool row_sum_supported(const NttTables &T) { return fast_log_h(T.log_r2, 1u << T.log_r1) != 0; }
+// the fused n-client sum kernel exists for every radix row kernel (two rounds, or three rounds of radix 8)
+static bool row_sum_supported(const NttTables &T) { return fast_row(T.log_r2, 1u << T.log_r1) != 0; }
 
 template <bool INV>
 static void launch_row(const NttIo &io0, const NttTables &T, uint32_t n_polys, const TailArgs &tail, const Lanes &ln,
@@ -1169,6 +1169,19 @@ static void launch_row_inner_fp_n(const InnerArgs &a, const NttTables &T, uint32
     }
 }
 
+static void launch_row3_inner_fp_n(const InnerArgs &a, const NttTables &T, uint32_t nparts, hipStream_t s) {
+    const dim3 grid(((1u << T.log_r1) / Row3::ROWS) * a.nsel * a.items);
+    switch (nparts) {
+        case 1: k_row3_inner_fp<1><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 2: k_row3_inner_fp<2><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 3: k_row3_inner_fp<3><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 4: k_row3_inner_fp<4><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 5: k_row3_inner_fp<5><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 6: k_row3_inner_fp<6><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
+    }
+}
+
 // S1-S4 of the hybrid key switch for `cnt` ciphertexts: ModUp digits of c1 (EvalKeySwitchPrecomputeCore) and their
 // inner product with the eval key over Q_l P (EvalFastKeySwitchCoreExt) -> til [cnt][2][ext][N].
 // With the radix kernels the fp64 Q limbs finish their forward transform inside k_row_inner_fp (digits stay on chip);
@@ -1178,17 +1191,18 @@ void Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u
     const uint32_t n = ps_.n, ext = nl + ps_.K, nparts = ps_.num_parts(nl), D = ps_.D;
     const char *fe = std::getenv("MKCKKS_FUSE_INNER");  // read per call: the tests run both paths in one process
     const bool fuse_env = !fe || std::atoi(fe) != 0;
-    const int row_h = fast_log_h(tabs_.log_r2, 1u << tabs_.log_r1);
+    const int row_h = fast_row(tabs_.log_r2, 1u << tabs_.log_r1);
     unsigned long long fp_mask = 0, all_mask = ext >= 64 ? ~0ull : ((1ull << ext) - 1);
     for (uint32_t i = 0; i < nl; ++i)
         if (tabs_.h_fp_of[i]) fp_mask |= 1ull << i;
-    const bool fuse = fuse_env && fp_mask != 0 && (row_h == 3 || row_h == 4) &&
+    const bool fuse = fuse_env && fp_mask != 0 && (row_h == 3 || row_h == 4 || row_h == 9) &&
                       fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0;
     modup_core(c1, ct_stride, coef, dig, cnt, nl, fuse);
     if (fuse) {
         InnerArgs a{dig, c1, evk, til, ct_stride, nl, ext, D, ps_.alpha, cnt, fp_mask,
                     (uint32_t)__builtin_popcountll(fp_mask)};
-        if (row_h == 4) launch_row_inner_fp_n<4>(a, tabs_, nparts, stream_);
+        if (row_h == 9) launch_row3_inner_fp_n(a, tabs_, nparts, stream_);
+        else if (row_h == 4) launch_row_inner_fp_n<4>(a, tabs_, nparts, stream_);
         else launch_row_inner_fp_n<3>(a, tabs_, nparts, stream_);
     }
     const unsigned long long mask = fuse ? (all_mask & ~fp_mask) : all_mask;
@@ -1218,6 +1232,17 @@ void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t c
     keyswitch_digits(c1, ct_stride, evk, coef, dig, til, cnt, nl);
     // S5: ApproxModDown of both components (2*cnt polynomials of ext limbs), + c0 on component 0
     moddown_core(til, pc, conv, out, (size_t)nl * n, ct, ct_stride, 2 * cnt, nl, accumulate);
+}
+
+static void launch_row3_tail_sum(SumArgs a, const NttTables &T, hipStream_t s) {
+    const uint32_t tiles = (1u << T.log_r1) / Row3::ROWS;
+    SumArgs ai = a, af = a;
+    ai.slot_mask = af.slot_mask = 0;
+    for (uint32_t i = 0; i < a.nl; ++i) (T.h_fp_of[i] ? af.slot_mask : ai.slot_mask) |= 1ull << i;
+    ai.nsel = (uint32_t)__builtin_popcountll(ai.slot_mask);
+    af.nsel = (uint32_t)__builtin_popcountll(af.slot_mask);
+    if (ai.nsel) k_row3_tail_sum<false><<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s>>>(ai, T);
+    if (af.nsel) k_row3_tail_sum<true><<<dim3(tiles * af.nsel * a.n_polys), NTT_THREADS, 0, s>>>(af, T);
 }
 
 template <int LOG_H>
@@ -1264,7 +1289,7 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
         return;
     }
     const u64 *fold = folded_scale(nl), *pinv = p_inverse(nl);
-    const int log_h = fast_log_h(tabs_.log_r2, 1u << tabs_.log_r1);
+    const int log_h = fast_row(tabs_.log_r2, 1u << tabs_.log_r1);  // 9: three-round kernels on 512-point rows
     for (uint32_t b0 = 0; b0 < n_ct; b0 += chunk_) {
         const uint32_t cnt = n_ct - b0 < chunk_ ? n_ct - b0 : chunk_;
         // arena: per client {til, conv}; per lane {coef, dig, pc}
@@ -1325,6 +1350,7 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
                       cts + ((size_t)c0 * n_ct + b0) * ct_words, out + (size_t)b0 * ct_words, pinv, pinv + nl,
                       w_conv, w_til, (size_t)n_ct * ct_words, ct_words, gcnt, nl, ext, 2 * cnt, 0, 0, c0 != 0 ? 1u : 0u};
             switch (log_h) {
+                case 9: launch_row3_tail_sum(a, tabs_, sum_stream); break;
                 case 4: launch_row_tail_sum<4>(a, tabs_, ps_.L, sum_stream); break;
                 case 3: launch_row_tail_sum<3>(a, tabs_, ps_.L, sum_stream); break;
                 default: launch_row_tail_sum<2>(a, tabs_, ps_.L, sum_stream); break;

@@ -1083,4 +1083,259 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T,
     }
 }
 
+// ---- fused kernels on 512-point rows (N = 2^17): the same fusions as k_row_tail_sum / k_row_inner_fp ----------
+// A wavefront owns ONE row (64 threads x 8 words) in every phase, so after the cooperative twiddle staging all LDS
+// hand-offs are wave-level.  8 words per thread keep the accumulators small (16-32 registers): these kernels run at
+// high occupancy.
+struct Row3Ctx {
+    u64 *lds, *twa, *twa_sh, *twb, *twb_sh;
+    int g, t, p, r;
+};
+// stage the round-A / round-B twiddles of the tile's 4 rows (cooperative; the caller synchronises the workgroup)
+MK_D void row3_stage_twiddles(const Row3Ctx &c, const u64 *tw, const u64 *tw_sh, uint32_t base0) {
+    constexpr int S = Row3::ROWS;
+    for (int e = threadIdx.x; e < Row3::TWA; e += NTT_THREADS) {
+        const int s = 31 - __clz(e / S + 1), off = e - S * ((1 << s) - 1);
+        const uint32_t idx = (base0 << s) + (uint32_t)off;
+        c.twa[e] = tw[idx];
+        c.twa_sh[e] = tw_sh[idx];
+    }
+    for (int e = threadIdx.x; e < Row3::TWB; e += NTT_THREADS) {
+        const int s = 31 - __clz(e / (S * 8) + 1), off = e - S * 8 * ((1 << s) - 1);
+        const uint32_t idx = ((base0 * 8) << s) + (uint32_t)off;
+        c.twb[e] = tw[idx];
+        c.twb_sh[e] = tw_sh[idx];
+    }
+}
+// forward transform of this wave's row: x[k] = word t + 64 k on entry; on exit x[k] = word 64 p + 8 r + k in the lazy
+// range of the arithmetic (wc / wpc: the thread's round-C twiddles, the same for every polynomial of the limb)
+template <bool FP>
+MK_D void row3_forward(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], const u64 (&wpc)[7], const LimbConst &lc) {
+    using TL = Row3;
+    constexpr int S = Row3::ROWS;
+    u64 w[7], wp[7];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int gg = 0; gg < (1 << s); ++gg) {
+            const int e = S * ((1 << s) - 1) + (c.g << s) + gg;
+            w[(1 << s) - 1 + gg] = c.twa[e];
+            wp[(1 << s) - 1 + gg] = c.twa_sh[e];
+        }
+    radix_forward_any<3, FP>(x, w, wp, lc);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c.lds[TL::at(c.g, c.t + 64 * k)] = x[k];
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = c.lds[TL::at(c.g, 64 * c.p + 8 * k + c.r)];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int gg = 0; gg < (1 << s); ++gg) {
+            const int e = S * 8 * ((1 << s) - 1) + ((c.g * 8 + c.p) << s) + gg;
+            w[(1 << s) - 1 + gg] = c.twb[e];
+            wp[(1 << s) - 1 + gg] = c.twb_sh[e];
+        }
+    radix_forward_any<3, FP>(x, w, wp, lc);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c.lds[TL::at(c.g, 64 * c.p + 8 * k + c.r)] = x[k];  // own words
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = c.lds[TL::at(c.g, 64 * c.p + 8 * c.r + k)];
+    radix_forward_any<3, FP>(x, wc, wpc, lc);
+}
+// i-th 16-byte access of this lane inside its wave's row (pair index into the 4-row tile)
+MK_D int row3_pair(int g, int t, int i) { return g * (Row3::R / 2) + t + 64 * i; }
+
+// ModDown row pass + tail + sum over clients (see k_row_tail_sum) on 512-point rows
+template <bool FP>
+__global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_sum(SumArgs a, NttTables T) {
+    using TL = Row3;
+    constexpr int R = TL::R, S = TL::ROWS, PAIRS = R / 2 / 64;
+    __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
+    Row3Ctx c;
+    c.lds = lds;
+    c.twa = lds + TL::WORDS;
+    c.twa_sh = c.twa + TL::TWA;
+    c.twb = c.twa_sh + TL::TWA;
+    c.twb_sh = c.twb + TL::TWB;
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
+    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
+    uint32_t grp, poly;
+    if (groups % 8 == 0) {
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / a.n_polys) * 8 + xcd;
+        poly = qidx % a.n_polys;
+    } else {
+        grp = blockIdx.x / a.n_polys;
+        poly = blockIdx.x % a.n_polys;
+    }
+    const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);
+    const LimbConst lc = T.limb[sl];
+    if ((lc.fp != 0) != FP) return;
+    const uint32_t row0 = (grp % tiles) * S;
+    c.g = threadIdx.x / 64;
+    c.t = threadIdx.x % 64;
+    c.p = c.t / 8;
+    c.r = c.t % 8;
+    const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
+    row3_stage_twiddles(c, tw, tw_sh, r1 + row0);
+    u64 wc[7], wpc[7];
+    load_round_twiddles<3>(tw, tw_sh, (r1 + row0 + c.g) * 64 + 8 * c.p + c.r, wc, wpc);
+    const u64 pi = a.pinv[sl], pi_sh = a.pinv_sh[sl];
+    const size_t tile_off = (size_t)row0 * R;
+    u64 *dst = a.out + ((size_t)poly * a.nl + sl) * n + tile_off;
+    ulong2 acc[PAIRS];
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i)
+        acc[i] = a.init_from_out ? reinterpret_cast<const ulong2 *>(dst)[row3_pair(c.g, c.t, i)] : ulong2{0, 0};
+    const u64 *src0 = a.conv + ((size_t)poly * a.nl + sl) * n + tile_off + (size_t)c.g * R + c.t;
+    u64 x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = ld_stream(src0 + 64 * k);
+    __syncthreads();  // twiddles staged
+    for (uint32_t cl = 0; cl < a.n_clients; ++cl) {
+        wave_lds_sync();  // previous client's tail finished reading this wave's row
+        row3_forward<FP>(x, c, wc, wpc, lc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            lds[TL::at(c.g, 64 * c.p + 8 * c.r + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
+        if (cl + 1 < a.n_clients) {
+            const u64 *nxt = src0 + (size_t)(cl + 1) * a.conv_cstride;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = ld_stream(nxt + 64 * k);
+        }
+        wave_lds_sync();
+        const u64 *tq = a.til + (size_t)cl * a.til_cstride + ((size_t)poly * a.ext + sl) * n + tile_off;
+        const u64 *c0 = (poly & 1) == 0
+                            ? a.cts + (size_t)cl * a.ct_cstride + (size_t)(poly >> 1) * a.ct_stride + (size_t)sl * n + tile_off
+                            : nullptr;
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = row3_pair(c.g, c.t, i);
+            const int xx = (2 * e) % R;
+            const ulong2 tt = ld_stream2(reinterpret_cast<const ulong2 *>(tq) + e);
+            ulong2 v;
+            v.x = shoup_mul(sub_mod(tt.x, lds[TL::at(c.g, xx)], lc.q), pi, pi_sh, lc.q);
+            v.y = shoup_mul(sub_mod(tt.y, lds[TL::at(c.g, xx + 1)], lc.q), pi, pi_sh, lc.q);
+            if (c0) {
+                const ulong2 z = ld_stream2(reinterpret_cast<const ulong2 *>(c0) + e);
+                v.x = add_mod(v.x, z.x, lc.q);
+                v.y = add_mod(v.y, z.y, lc.q);
+            }
+            acc[i].x = add_mod(acc[i].x, v.x, lc.q);
+            acc[i].y = add_mod(acc[i].y, v.y, lc.q);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[row3_pair(c.g, c.t, i)] = acc[i];
+}
+
+// ModUp row pass + eval-key inner product on the fp64 Q limbs (see k_row_inner_fp) on 512-point rows
+template <int NPARTS>
+__global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, NttTables T) {
+    using TL = Row3;
+    constexpr int R = TL::R, S = TL::ROWS, PAIRS = R / 2 / 64;
+    __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
+    Row3Ctx c;
+    c.lds = lds;
+    c.twa = lds + TL::WORDS;
+    c.twa_sh = c.twa + TL::TWA;
+    c.twb = c.twa_sh + TL::TWA;
+    c.twb_sh = c.twb + TL::TWB;
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
+    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
+    uint32_t grp, item;
+    if (groups % 8 == 0) {
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / a.items) * 8 + xcd;
+        item = qidx % a.items;
+    } else {
+        grp = blockIdx.x / a.items;
+        item = blockIdx.x % a.items;
+    }
+    const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);
+    const LimbConst lc = T.limb[sl];
+    const int own = (int)(sl / a.alpha);
+    const uint32_t row0 = (grp % tiles) * S;
+    c.g = threadIdx.x / 64;
+    c.t = threadIdx.x % 64;
+    c.p = c.t / 8;
+    c.r = c.t % 8;
+    const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
+    row3_stage_twiddles(c, tw, tw_sh, r1 + row0);
+    u64 wc[7], wpc[7];
+    load_round_twiddles<3>(tw, tw_sh, (r1 + row0 + c.g) * 64 + 8 * c.p + c.r, wc, wpc);
+    const size_t tile_off = (size_t)row0 * R;
+    const double q = lc.qd, qinv = lc.qinv;
+    int jn = own == 0 ? 1 : 0;
+    const u64 *dig0 = a.dig + ((size_t)item * NPARTS * a.ext + sl) * n + tile_off + (size_t)c.g * R + c.t;
+    u64 x[8];
+    if (jn < NPARTS) {
+        const u64 *src = dig0 + (size_t)jn * a.ext * n;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + 64 * k);
+    }
+    double2 acc0[PAIRS], acc1[PAIRS];
+    {
+        const u64 *y0 = a.c1 + (size_t)item * a.c1_stride + (size_t)sl * n + tile_off;
+        const u64 *e0 = a.evk + (((size_t)own * 2 + 0) * a.D + sl) * n + tile_off;
+        const u64 *e1 = a.evk + (((size_t)own * 2 + 1) * a.D + sl) * n + tile_off;
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = row3_pair(c.g, c.t, i);
+            const ulong2 yy = ld_stream2(reinterpret_cast<const ulong2 *>(y0) + e);
+            const ulong2 b = reinterpret_cast<const ulong2 *>(e0)[e];
+            const ulong2 cc = reinterpret_cast<const ulong2 *>(e1)[e];
+            const double yx = u52_to_double(yy.x), yz = u52_to_double(yy.y);
+            acc0[i].x = fp_mulmod_any(yx, u52_to_double(b.x), q, qinv);
+            acc0[i].y = fp_mulmod_any(yz, u52_to_double(b.y), q, qinv);
+            acc1[i].x = fp_mulmod_any(yx, u52_to_double(cc.x), q, qinv);
+            acc1[i].y = fp_mulmod_any(yz, u52_to_double(cc.y), q, qinv);
+        }
+    }
+    __syncthreads();  // twiddles staged
+#pragma unroll 1
+    for (int dj = jn; dj < NPARTS; dj = jn) {
+        jn = dj + 1 == own ? dj + 2 : dj + 1;
+        wave_lds_sync();  // previous digit's products finished reading this wave's row
+        row3_forward<true>(x, c, wc, wpc, lc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 64 * c.p + 8 * c.r + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));
+        if (jn < NPARTS) {
+            const u64 *src = dig0 + (size_t)jn * a.ext * n;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + 64 * k);
+        }
+        wave_lds_sync();
+        const u64 *e0 = a.evk + (((size_t)dj * 2 + 0) * a.D + sl) * n + tile_off;
+        const u64 *e1 = a.evk + (((size_t)dj * 2 + 1) * a.D + sl) * n + tile_off;
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = row3_pair(c.g, c.t, i);
+            const int xx = (2 * e) % R;
+            const ulong2 b = reinterpret_cast<const ulong2 *>(e0)[e];
+            const ulong2 cc = reinterpret_cast<const ulong2 *>(e1)[e];
+            const double yx = bitsd(lds[TL::at(c.g, xx)]), yz = bitsd(lds[TL::at(c.g, xx + 1)]);
+            acc0[i].x += fp_mulmod_any(yx, u52_to_double(b.x), q, qinv);
+            acc0[i].y += fp_mulmod_any(yz, u52_to_double(b.y), q, qinv);
+            acc1[i].x += fp_mulmod_any(yx, u52_to_double(cc.x), q, qinv);
+            acc1[i].y += fp_mulmod_any(yz, u52_to_double(cc.y), q, qinv);
+        }
+    }
+    u64 *t0 = a.til + (((size_t)item * 2 + 0) * a.ext + sl) * n + tile_off;
+    u64 *t1 = a.til + (((size_t)item * 2 + 1) * a.ext + sl) * n + tile_off;
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+        const int e = row3_pair(c.g, c.t, i);
+        ulong2 r0, r1v;
+        r0.x = fp_to_canonical(acc0[i].x, q, qinv);
+        r0.y = fp_to_canonical(acc0[i].y, q, qinv);
+        r1v.x = fp_to_canonical(acc1[i].x, q, qinv);
+        r1v.y = fp_to_canonical(acc1[i].y, q, qinv);
+        st_stream2(reinterpret_cast<ulong2 *>(t0) + e, r0);
+        st_stream2(reinterpret_cast<ulong2 *>(t1) + e, r1v);
+    }
+}
+
 }  // namespace mk

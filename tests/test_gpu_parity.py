@@ -351,7 +351,9 @@ def test_reencrypt_accumulate(ctxs, name, nl):
                                          ("c5s", 20, 2, 1), ("n11", 4, 3, 2), ("tiny", 5, 2, 19),
                                          # the N=2^16 sum kernel takes clients two at a time: even / odd counts, one
                                          # and two full pairs, a lower level (nl < L)
-                                         ("c3", 12, 4, 1), ("c3", 12, 5, 1), ("c3", 11, 2, 2), ("c3", 12, 1, 1)])
+                                         ("c3", 12, 4, 1), ("c3", 12, 5, 1), ("c3", 11, 2, 2), ("c3", 12, 1, 1),
+                                         # N = 2^17: 512-point rows, three-round fused sum / inner-product kernels
+                                         ("n17", 4, 3, 2), ("n17", 3, 2, 1)])
 def test_reencrypt_sum(ctxs, name, nl, C, B):
     # sum over clients of ReEncrypt(ct_c, evk_c) in one call == EvalAdd chain of the individual re-encryptions
     g, o = ctxs(name)

@@ -1169,15 +1169,23 @@ static void launch_row_inner_fp_n(const InnerArgs &a, const NttTables &T, uint32
     }
 }
 
+// 256-point rows have two implementations of the fused kernels: two rounds of radix 16 (16 words per thread, 2 waves
+// per SIMD) and three rounds 8 x 8 x 4 (8 words per thread, 3 waves per SIMD); MKCKKS_ROW3X picks
+static bool three_round_256() {
+    const char *e = std::getenv("MKCKKS_ROW3X");
+    return e && std::atoi(e) != 0;
+}
+
+template <int LOGC>
 static void launch_row3_inner_fp_n(const InnerArgs &a, const NttTables &T, uint32_t nparts, hipStream_t s) {
-    const dim3 grid(((1u << T.log_r1) / Row3::ROWS) * a.nsel * a.items);
+    const dim3 grid(((1u << T.log_r1) / RowT<LOGC>::ROWS) * a.nsel * a.items);
     switch (nparts) {
-        case 1: k_row3_inner_fp<1><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 2: k_row3_inner_fp<2><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 3: k_row3_inner_fp<3><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 4: k_row3_inner_fp<4><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 5: k_row3_inner_fp<5><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 6: k_row3_inner_fp<6><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 1: k_row3_inner_fp<1, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 2: k_row3_inner_fp<2, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 3: k_row3_inner_fp<3, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 4: k_row3_inner_fp<4, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 5: k_row3_inner_fp<5, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 6: k_row3_inner_fp<6, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
         default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
     }
 }
@@ -1201,7 +1209,8 @@ void Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u
     if (fuse) {
         InnerArgs a{dig, c1, evk, til, ct_stride, nl, ext, D, ps_.alpha, cnt, fp_mask,
                     (uint32_t)__builtin_popcountll(fp_mask)};
-        if (row_h == 9) launch_row3_inner_fp_n(a, tabs_, nparts, stream_);
+        if (row_h == 9) launch_row3_inner_fp_n<3>(a, tabs_, nparts, stream_);
+        else if (row_h == 4 && three_round_256()) launch_row3_inner_fp_n<2>(a, tabs_, nparts, stream_);
         else if (row_h == 4) launch_row_inner_fp_n<4>(a, tabs_, nparts, stream_);
         else launch_row_inner_fp_n<3>(a, tabs_, nparts, stream_);
     }
@@ -1234,16 +1243,18 @@ void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t c
     moddown_core(til, pc, conv, out, (size_t)nl * n, ct, ct_stride, 2 * cnt, nl, accumulate);
 }
 
+template <int LOGC>
 static void launch_row3_tail_sum(SumArgs a, const NttTables &T, hipStream_t s) {
-    const uint32_t tiles = (1u << T.log_r1) / Row3::ROWS;
+    const uint32_t tiles = (1u << T.log_r1) / RowT<LOGC>::ROWS;
     SumArgs ai = a, af = a;
     ai.slot_mask = af.slot_mask = 0;
     for (uint32_t i = 0; i < a.nl; ++i) (T.h_fp_of[i] ? af.slot_mask : ai.slot_mask) |= 1ull << i;
     ai.nsel = (uint32_t)__builtin_popcountll(ai.slot_mask);
     af.nsel = (uint32_t)__builtin_popcountll(af.slot_mask);
-    if (ai.nsel) k_row3_tail_sum<false><<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s>>>(ai, T);
-    if (af.nsel) k_row3_tail_sum<true><<<dim3(tiles * af.nsel * a.n_polys), NTT_THREADS, 0, s>>>(af, T);
+    if (ai.nsel) k_row3_tail_sum<false, LOGC><<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s>>>(ai, T);
+    if (af.nsel) k_row3_tail_sum<true, LOGC><<<dim3(tiles * af.nsel * a.n_polys), NTT_THREADS, 0, s>>>(af, T);
 }
+
 
 template <int LOG_H>
 static void launch_row_tail_sum(SumArgs a, const NttTables &T, uint32_t L, hipStream_t s) {
@@ -1350,8 +1361,11 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
                       cts + ((size_t)c0 * n_ct + b0) * ct_words, out + (size_t)b0 * ct_words, pinv, pinv + nl,
                       w_conv, w_til, (size_t)n_ct * ct_words, ct_words, gcnt, nl, ext, 2 * cnt, 0, 0, c0 != 0 ? 1u : 0u};
             switch (log_h) {
-                case 9: launch_row3_tail_sum(a, tabs_, sum_stream); break;
-                case 4: launch_row_tail_sum<4>(a, tabs_, ps_.L, sum_stream); break;
+                case 9: launch_row3_tail_sum<3>(a, tabs_, sum_stream); break;
+                case 4:
+                    if (three_round_256()) launch_row3_tail_sum<2>(a, tabs_, sum_stream);
+                    else launch_row_tail_sum<4>(a, tabs_, ps_.L, sum_stream);
+                    break;
                 case 3: launch_row_tail_sum<3>(a, tabs_, ps_.L, sum_stream); break;
                 default: launch_row_tail_sum<2>(a, tabs_, ps_.L, sum_stream); break;
             }

@@ -923,11 +923,17 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
 // A workgroup owns 4 consecutive rows (2048 contiguous words); two LDS exchanges; layout x + x/8 per row (stride
 // 576) is conflict-free for all three access patterns.  Round A and B twiddles are shared by 64 resp. 8 threads and
 // go through LDS (contiguous runs over the tile), round C twiddles are per thread.
-struct Row3 {
-    static constexpr int H = 8, ROWS = 4, R = 512, RS = 576, WORDS = ROWS * RS;
+// Generic three-round geometry: R = 8 * 8 * C words per row with C = 2^LOGC in {4, 8} (256- and 512-point rows),
+// position x = 8C a + C b + c, TPR = R/8 threads per row (8 words each), 256/TPR rows per workgroup.  The last round
+// is one radix-8 (C = 8) or two radix-4 groups (C = 4) on the thread's 8 CONTIGUOUS words 8u..8u+7.
+template <int LOGC>
+struct RowT {
+    static constexpr int H = 8, C = 1 << LOGC, R = 64 * C, TPR = R / 8, ROWS = NTT_THREADS / TPR;
+    static constexpr int RS = R + R / 8, WORDS = ROWS * RS;
     static constexpr int TWA = ROWS * 7, TWB = ROWS * 8 * 7;  // per table
     static MK_D int at(int g, int x) { return g * RS + x + (x >> 3); }
 };
+using Row3 = RowT<3>;
 template <bool INV, bool FP>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T, TailArgs tail) {
     using TL = Row3;
@@ -1089,30 +1095,51 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T,
 // high occupancy.
 struct Row3Ctx {
     u64 *lds, *twa, *twa_sh, *twb, *twb_sh;
-    int g, t, p, r;
+    int g, t;  // row of the tile, thread inside the row
 };
 // stage the round-A / round-B twiddles of the tile's 4 rows (cooperative; the caller synchronises the workgroup)
+template <int LOGC>
 MK_D void row3_stage_twiddles(const Row3Ctx &c, const u64 *tw, const u64 *tw_sh, uint32_t base0) {
-    constexpr int S = Row3::ROWS;
-    for (int e = threadIdx.x; e < Row3::TWA; e += NTT_THREADS) {
+    constexpr int S = RowT<LOGC>::ROWS;
+    for (int e = threadIdx.x; e < RowT<LOGC>::TWA; e += NTT_THREADS) {
         const int s = 31 - __clz(e / S + 1), off = e - S * ((1 << s) - 1);
         const uint32_t idx = (base0 << s) + (uint32_t)off;
         c.twa[e] = tw[idx];
         c.twa_sh[e] = tw_sh[idx];
     }
-    for (int e = threadIdx.x; e < Row3::TWB; e += NTT_THREADS) {
+    for (int e = threadIdx.x; e < RowT<LOGC>::TWB; e += NTT_THREADS) {
         const int s = 31 - __clz(e / (S * 8) + 1), off = e - S * 8 * ((1 << s) - 1);
         const uint32_t idx = ((base0 * 8) << s) + (uint32_t)off;
         c.twb[e] = tw[idx];
         c.twb_sh[e] = tw_sh[idx];
     }
 }
-// forward transform of this wave's row: x[k] = word t + 64 k on entry; on exit x[k] = word 64 p + 8 r + k in the lazy
-// range of the arithmetic (wc / wpc: the thread's round-C twiddles, the same for every polynomial of the limb)
-template <bool FP>
+// round-C twiddles of a thread (the same for every polynomial of the limb): one radix-8 set, or two radix-4 sets
+template <int LOGC>
+MK_D void row3_load_c_twiddles(const u64 *tw, const u64 *tw_sh, uint32_t base, int t, u64 (&wc)[7], u64 (&wpc)[7]) {
+    if (LOGC == 3) {
+        load_round_twiddles<3>(tw, tw_sh, base * 64 + (uint32_t)t, wc, wpc);
+    } else {
+        u64 a[3], ap[3], b[3], bp[3];
+        load_round_twiddles<2>(tw, tw_sh, base * 64 + 2u * (uint32_t)t, a, ap);
+        load_round_twiddles<2>(tw, tw_sh, base * 64 + 2u * (uint32_t)t + 1u, b, bp);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            wc[i] = a[i];
+            wpc[i] = ap[i];
+            wc[3 + i] = b[i];
+            wpc[3 + i] = bp[i];
+        }
+        wc[6] = wpc[6] = 0;
+    }
+}
+// forward transform of this thread's row: x[k] = word t + TPR k on entry; on exit x[k] = word 8 t + k in the lazy
+// range of the arithmetic
+template <bool FP, int LOGC>
 MK_D void row3_forward(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], const u64 (&wpc)[7], const LimbConst &lc) {
-    using TL = Row3;
-    constexpr int S = Row3::ROWS;
+    using TL = RowT<LOGC>;
+    constexpr int S = TL::ROWS, TPR = TL::TPR, C = TL::C;
+    const int a = c.t / C, cc = c.t % C;
     u64 w[7], wp[7];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -1124,34 +1151,48 @@ MK_D void row3_forward(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], const 
         }
     radix_forward_any<3, FP>(x, w, wp, lc);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) c.lds[TL::at(c.g, c.t + 64 * k)] = x[k];
+    for (int k = 0; k < 8; ++k) c.lds[TL::at(c.g, c.t + TPR * k)] = x[k];
     wave_lds_sync();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = c.lds[TL::at(c.g, 64 * c.p + 8 * k + c.r)];
+    for (int k = 0; k < 8; ++k) x[k] = c.lds[TL::at(c.g, 8 * C * a + C * k + cc)];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int gg = 0; gg < (1 << s); ++gg) {
-            const int e = S * 8 * ((1 << s) - 1) + ((c.g * 8 + c.p) << s) + gg;
+            const int e = S * 8 * ((1 << s) - 1) + ((c.g * 8 + a) << s) + gg;
             w[(1 << s) - 1 + gg] = c.twb[e];
             wp[(1 << s) - 1 + gg] = c.twb_sh[e];
         }
     radix_forward_any<3, FP>(x, w, wp, lc);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) c.lds[TL::at(c.g, 64 * c.p + 8 * k + c.r)] = x[k];  // own words
+    for (int k = 0; k < 8; ++k) c.lds[TL::at(c.g, 8 * C * a + C * k + cc)] = x[k];  // own words
     wave_lds_sync();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = c.lds[TL::at(c.g, 64 * c.p + 8 * c.r + k)];
-    radix_forward_any<3, FP>(x, wc, wpc, lc);
+    for (int k = 0; k < 8; ++k) x[k] = c.lds[TL::at(c.g, 8 * c.t + k)];
+    if (LOGC == 3) {
+        radix_forward_any<3, FP>(x, wc, wpc, lc);
+    } else {  // two radix-4 groups: words 8t..8t+3 and 8t+4..8t+7
+        u64 y0[4] = {x[0], x[1], x[2], x[3]}, y1[4] = {x[4], x[5], x[6], x[7]};
+        const u64 w0[3] = {wc[0], wc[1], wc[2]}, wp0[3] = {wpc[0], wpc[1], wpc[2]};
+        const u64 w1[3] = {wc[3], wc[4], wc[5]}, wp1[3] = {wpc[3], wpc[4], wpc[5]};
+        radix_forward_any<2, FP>(y0, w0, wp0, lc);
+        radix_forward_any<2, FP>(y1, w1, wp1, lc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            x[k] = y0[k];
+            x[4 + k] = y1[k];
+        }
+    }
 }
 // i-th 16-byte access of this lane inside its wave's row (pair index into the 4-row tile)
-MK_D int row3_pair(int g, int t, int i) { return g * (Row3::R / 2) + t + 64 * i; }
+template <int LOGC>
+MK_D int row3_pair(int g, int t, int i) { return g * (RowT<LOGC>::R / 2) + t + RowT<LOGC>::TPR * i; }
 
 // ModDown row pass + tail + sum over clients (see k_row_tail_sum) on 512-point rows
-template <bool FP>
+template <bool FP, int LOGC>
 __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_sum(SumArgs a, NttTables T) {
-    using TL = Row3;
-    constexpr int R = TL::R, S = TL::ROWS, PAIRS = R / 2 / 64;
+    using TL = RowT<LOGC>;
+    constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
     __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
     Row3Ctx c;
     c.lds = lds;
@@ -1174,36 +1215,34 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_sum(SumArgs a, Ntt
     const LimbConst lc = T.limb[sl];
     if ((lc.fp != 0) != FP) return;
     const uint32_t row0 = (grp % tiles) * S;
-    c.g = threadIdx.x / 64;
-    c.t = threadIdx.x % 64;
-    c.p = c.t / 8;
-    c.r = c.t % 8;
+    c.g = threadIdx.x / TPR;
+    c.t = threadIdx.x % TPR;
     const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
-    row3_stage_twiddles(c, tw, tw_sh, r1 + row0);
+    row3_stage_twiddles<LOGC>(c, tw, tw_sh, r1 + row0);
     u64 wc[7], wpc[7];
-    load_round_twiddles<3>(tw, tw_sh, (r1 + row0 + c.g) * 64 + 8 * c.p + c.r, wc, wpc);
+    row3_load_c_twiddles<LOGC>(tw, tw_sh, r1 + row0 + c.g, c.t, wc, wpc);
     const u64 pi = a.pinv[sl], pi_sh = a.pinv_sh[sl];
     const size_t tile_off = (size_t)row0 * R;
     u64 *dst = a.out + ((size_t)poly * a.nl + sl) * n + tile_off;
     ulong2 acc[PAIRS];
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i)
-        acc[i] = a.init_from_out ? reinterpret_cast<const ulong2 *>(dst)[row3_pair(c.g, c.t, i)] : ulong2{0, 0};
+        acc[i] = a.init_from_out ? reinterpret_cast<const ulong2 *>(dst)[row3_pair<LOGC>(c.g, c.t, i)] : ulong2{0, 0};
     const u64 *src0 = a.conv + ((size_t)poly * a.nl + sl) * n + tile_off + (size_t)c.g * R + c.t;
     u64 x[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = ld_stream(src0 + 64 * k);
+    for (int k = 0; k < 8; ++k) x[k] = ld_stream(src0 + TPR * k);
     __syncthreads();  // twiddles staged
     for (uint32_t cl = 0; cl < a.n_clients; ++cl) {
         wave_lds_sync();  // previous client's tail finished reading this wave's row
-        row3_forward<FP>(x, c, wc, wpc, lc);
+        row3_forward<FP, LOGC>(x, c, wc, wpc, lc);
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            lds[TL::at(c.g, 64 * c.p + 8 * c.r + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
+            lds[TL::at(c.g, 8 * c.t + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
         if (cl + 1 < a.n_clients) {
             const u64 *nxt = src0 + (size_t)(cl + 1) * a.conv_cstride;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = ld_stream(nxt + 64 * k);
+            for (int k = 0; k < 8; ++k) x[k] = ld_stream(nxt + TPR * k);
         }
         wave_lds_sync();
         const u64 *tq = a.til + (size_t)cl * a.til_cstride + ((size_t)poly * a.ext + sl) * n + tile_off;
@@ -1212,7 +1251,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_sum(SumArgs a, Ntt
                             : nullptr;
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
-            const int e = row3_pair(c.g, c.t, i);
+            const int e = row3_pair<LOGC>(c.g, c.t, i);
             const int xx = (2 * e) % R;
             const ulong2 tt = ld_stream2(reinterpret_cast<const ulong2 *>(tq) + e);
             ulong2 v;
@@ -1228,14 +1267,14 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_sum(SumArgs a, Ntt
         }
     }
 #pragma unroll
-    for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[row3_pair(c.g, c.t, i)] = acc[i];
+    for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[row3_pair<LOGC>(c.g, c.t, i)] = acc[i];
 }
 
 // ModUp row pass + eval-key inner product on the fp64 Q limbs (see k_row_inner_fp) on 512-point rows
-template <int NPARTS>
+template <int NPARTS, int LOGC>
 __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, NttTables T) {
-    using TL = Row3;
-    constexpr int R = TL::R, S = TL::ROWS, PAIRS = R / 2 / 64;
+    using TL = RowT<LOGC>;
+    constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
     __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
     Row3Ctx c;
     c.lds = lds;
@@ -1258,14 +1297,12 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, N
     const LimbConst lc = T.limb[sl];
     const int own = (int)(sl / a.alpha);
     const uint32_t row0 = (grp % tiles) * S;
-    c.g = threadIdx.x / 64;
-    c.t = threadIdx.x % 64;
-    c.p = c.t / 8;
-    c.r = c.t % 8;
+    c.g = threadIdx.x / TPR;
+    c.t = threadIdx.x % TPR;
     const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
-    row3_stage_twiddles(c, tw, tw_sh, r1 + row0);
+    row3_stage_twiddles<LOGC>(c, tw, tw_sh, r1 + row0);
     u64 wc[7], wpc[7];
-    load_round_twiddles<3>(tw, tw_sh, (r1 + row0 + c.g) * 64 + 8 * c.p + c.r, wc, wpc);
+    row3_load_c_twiddles<LOGC>(tw, tw_sh, r1 + row0 + c.g, c.t, wc, wpc);
     const size_t tile_off = (size_t)row0 * R;
     const double q = lc.qd, qinv = lc.qinv;
     int jn = own == 0 ? 1 : 0;
@@ -1274,7 +1311,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, N
     if (jn < NPARTS) {
         const u64 *src = dig0 + (size_t)jn * a.ext * n;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + 64 * k);
+        for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + TPR * k);
     }
     double2 acc0[PAIRS], acc1[PAIRS];
     {
@@ -1283,7 +1320,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, N
         const u64 *e1 = a.evk + (((size_t)own * 2 + 1) * a.D + sl) * n + tile_off;
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
-            const int e = row3_pair(c.g, c.t, i);
+            const int e = row3_pair<LOGC>(c.g, c.t, i);
             const ulong2 yy = ld_stream2(reinterpret_cast<const ulong2 *>(y0) + e);
             const ulong2 b = reinterpret_cast<const ulong2 *>(e0)[e];
             const ulong2 cc = reinterpret_cast<const ulong2 *>(e1)[e];
@@ -1299,20 +1336,20 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, N
     for (int dj = jn; dj < NPARTS; dj = jn) {
         jn = dj + 1 == own ? dj + 2 : dj + 1;
         wave_lds_sync();  // previous digit's products finished reading this wave's row
-        row3_forward<true>(x, c, wc, wpc, lc);
+        row3_forward<true, LOGC>(x, c, wc, wpc, lc);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 64 * c.p + 8 * c.r + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));
+        for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 8 * c.t + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));
         if (jn < NPARTS) {
             const u64 *src = dig0 + (size_t)jn * a.ext * n;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + 64 * k);
+            for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + TPR * k);
         }
         wave_lds_sync();
         const u64 *e0 = a.evk + (((size_t)dj * 2 + 0) * a.D + sl) * n + tile_off;
         const u64 *e1 = a.evk + (((size_t)dj * 2 + 1) * a.D + sl) * n + tile_off;
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
-            const int e = row3_pair(c.g, c.t, i);
+            const int e = row3_pair<LOGC>(c.g, c.t, i);
             const int xx = (2 * e) % R;
             const ulong2 b = reinterpret_cast<const ulong2 *>(e0)[e];
             const ulong2 cc = reinterpret_cast<const ulong2 *>(e1)[e];
@@ -1327,7 +1364,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, N
     u64 *t1 = a.til + (((size_t)item * 2 + 1) * a.ext + sl) * n + tile_off;
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
-        const int e = row3_pair(c.g, c.t, i);
+        const int e = row3_pair<LOGC>(c.g, c.t, i);
         ulong2 r0, r1v;
         r0.x = fp_to_canonical(acc0[i].x, q, qinv);
         r0.y = fp_to_canonical(acc0[i].y, q, qinv);

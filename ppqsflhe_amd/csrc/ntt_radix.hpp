@@ -14,8 +14,12 @@
 // Every kernel exists in two arithmetic instances (template parameter FP): integer (Shoup/Harvey lazy butterflies on
 // v_mad_u64_u32) for the 60-bit limbs and fp64 (exact FMA products, see modarith.hpp) for limbs below 1.25 * 2^50;
 // the host launches each instance over the limbs of its class.  512-point rows (N = 2^17) use three rounds of
-// radix 8 (k_ntt_row3).  k_conv_col fuses the approximate base conversion into the forward column pass,
-// k_row_tail_sum the ModDown tail and the sum over clients into the forward row pass.
+// radix 8 (k_ntt_row3).  Fused kernels: k_conv_col (approximate base conversion + forward column pass),
+// k_row_inner_fp (forward row pass of the converted digits + eval-key inner product, fp64 limbs), k_row_tail_sum /
+// k_row_tail_sum2 (forward row pass + ModDown tail + sum over clients), and their three-round counterparts
+// k_row3_inner_fp / k_row3_tail_sum for 512-point (and optionally 256-point) rows.  In every row kernel a wavefront
+// owns complete rows, so LDS hand-offs are wave-level (wave_lds_sync) and the kernels contain no workgroup barrier
+// after the twiddle staging.
 #pragma once
 #include "modarith.hpp"
 #include "ntt_kernels.hpp"

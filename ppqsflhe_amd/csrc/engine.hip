@@ -478,6 +478,9 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
         MK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
         for (auto &st : extra_lane_) MK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         for (auto &ev : ev_lane_) MK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (auto &st : aux_stream_) MK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (auto &ev : ev_conv_) MK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (auto &ev : ev_aux_) MK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     MK_HIP(hipMalloc(&d_limb_, D * sizeof(LimbConst)));
     MK_HIP(hipMemcpy(d_limb_, ps_.limb.data(), D * sizeof(LimbConst), hipMemcpyHostToDevice));
@@ -557,6 +560,12 @@ Engine::~Engine() {
     for (auto st : extra_lane_)
         if (st) (void)hipStreamDestroy(st);
     for (auto ev : ev_lane_)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto st : aux_stream_)
+        if (st) (void)hipStreamDestroy(st);
+    for (auto ev : ev_conv_)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto ev : ev_aux_)
         if (ev) (void)hipEventDestroy(ev);
 }
 
@@ -1036,7 +1045,7 @@ const u64 *Engine::p_inverse(uint32_t nl) {
 // EvalKeySwitchPrecomputeCore on `cnt` polynomials c1 (items ct_stride apart): fills the converted limbs of
 // dig[item][part][ext][N] in EVALUATION format; the digits' own limbs are NOT copied (readers take them from c1).
 void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, uint32_t cnt, uint32_t nl,
-                        bool rows_int_only) {
+                        bool rows_int_only, hipEvent_t conv_done) {
     const uint32_t n = ps_.n, ext = nl + ps_.K, nparts = ps_.num_parts(nl), D = ps_.D;
     const u64 *fold = folded_scale(nl);
     // the fused conversion kernel exists when the column pass has a radix kernel; it reads packed 30-bit halves
@@ -1053,7 +1062,9 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
     if (fused) {
         // S3b: one row pass over every converted limb of every digit (own limbs skipped)
         NttIo row{dig, dig, (size_t)ext * n, (size_t)ext * n, 0, 0, 0, ext, nl, nparts, ps_.alpha};
-        // (rows_int_only: the fp64 limbs finish their transform inside the fused inner-product kernel)
+        // (rows_int_only: the fp64 limbs finish their transform inside the fused inner-product kernel, which may
+        // start as soon as the conversions are done: conv_done)
+        if (conv_done) MK_HIP(hipEventRecord(conv_done, stream_));
         launch_row<false>(row, tabs_, cnt * nparts, TailArgs{}, lanes(), rows_int_only ? 1u : 3u);
         MK_HIP(hipGetLastError());
         return;
@@ -1205,14 +1216,24 @@ void Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u
         if (tabs_.h_fp_of[i]) fp_mask |= 1ull << i;
     const bool fuse = fuse_env && fp_mask != 0 && (row_h == 3 || row_h == 4 || row_h == 9) &&
                       fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0;
-    modup_core(c1, ct_stride, coef, dig, cnt, nl, fuse);
+    const char *fk = std::getenv("MKCKKS_INNER_FORK");
+    const bool fork = fuse && aux_stream_[0] != nullptr && fk && std::atoi(fk) != 0;  // measured: -2.7 %, off
+    const uint32_t lane = cur_lane_ < MAX_SUM_LANES ? cur_lane_ : 0;
+    modup_core(c1, ct_stride, coef, dig, cnt, nl, fuse, fork ? ev_conv_[lane] : nullptr);
     if (fuse) {
+        // the fused fp64 kernel and the integer row pass + inner product touch disjoint limbs: side by side
+        hipStream_t fs = stream_;
+        if (fork) {
+            fs = aux_stream_[lane];
+            MK_HIP(hipStreamWaitEvent(fs, ev_conv_[lane], 0));
+        }
         InnerArgs a{dig, c1, evk, til, ct_stride, nl, ext, D, ps_.alpha, cnt, fp_mask,
                     (uint32_t)__builtin_popcountll(fp_mask)};
-        if (row_h == 9) launch_row3_inner_fp_n<3>(a, tabs_, nparts, stream_);
-        else if (row_h == 4 && three_round_256()) launch_row3_inner_fp_n<2>(a, tabs_, nparts, stream_);
-        else if (row_h == 4) launch_row_inner_fp_n<4>(a, tabs_, nparts, stream_);
-        else launch_row_inner_fp_n<3>(a, tabs_, nparts, stream_);
+        if (row_h == 9) launch_row3_inner_fp_n<3>(a, tabs_, nparts, fs);
+        else if (row_h == 4 && three_round_256()) launch_row3_inner_fp_n<2>(a, tabs_, nparts, fs);
+        else if (row_h == 4) launch_row_inner_fp_n<4>(a, tabs_, nparts, fs);
+        else launch_row_inner_fp_n<3>(a, tabs_, nparts, fs);
+        if (fork) MK_HIP(hipEventRecord(ev_aux_[lane], fs));
     }
     const unsigned long long mask = fuse ? (all_mask & ~fp_mask) : all_mask;
     EwGeom g{n, nl, ps_.L};
@@ -1225,6 +1246,7 @@ void Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u
         case 6: launch_inner<6>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, mask, stream_); break;
         default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
     }
+    if (fork) MK_HIP(hipStreamWaitEvent(stream_, ev_aux_[lane], 0));
     MK_HIP(hipGetLastError());
 }
 
@@ -1244,20 +1266,20 @@ void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t c
 }
 
 template <int LOGC>
-static void launch_row3_tail_sum(SumArgs a, const NttTables &T, hipStream_t s) {
+static void launch_row3_tail_sum(SumArgs a, const NttTables &T, hipStream_t s, hipStream_t s_int) {
     const uint32_t tiles = (1u << T.log_r1) / RowT<LOGC>::ROWS;
     SumArgs ai = a, af = a;
     ai.slot_mask = af.slot_mask = 0;
     for (uint32_t i = 0; i < a.nl; ++i) (T.h_fp_of[i] ? af.slot_mask : ai.slot_mask) |= 1ull << i;
     ai.nsel = (uint32_t)__builtin_popcountll(ai.slot_mask);
     af.nsel = (uint32_t)__builtin_popcountll(af.slot_mask);
-    if (ai.nsel) k_row3_tail_sum<false, LOGC><<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s>>>(ai, T);
+    if (ai.nsel) k_row3_tail_sum<false, LOGC><<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s_int>>>(ai, T);
     if (af.nsel) k_row3_tail_sum<true, LOGC><<<dim3(tiles * af.nsel * a.n_polys), NTT_THREADS, 0, s>>>(af, T);
 }
 
 
 template <int LOG_H>
-static void launch_row_tail_sum(SumArgs a, const NttTables &T, uint32_t L, hipStream_t s) {
+static void launch_row_tail_sum(SumArgs a, const NttTables &T, uint32_t L, hipStream_t s, hipStream_t s_int) {
     const uint32_t tiles = (1u << T.log_r1) / (256u >> LOG_H);
     SumArgs ai = a, af = a;
     ai.slot_mask = af.slot_mask = 0;
@@ -1271,16 +1293,16 @@ static void launch_row_tail_sum(SumArgs a, const NttTables &T, uint32_t L, hipSt
     const char *pe = std::getenv("MKCKKS_SUM_PAIR");  // read per call: the tests run both kernels in one process
     const bool pair = !pe || std::atoi(pe) != 0;
     if (pair && LOG_H == 4) {
-        if (ai.nsel) k_row_tail_sum2<LOG_H, false><<<gi, NTT_THREADS, 0, s>>>(ai, T);
+        if (ai.nsel) k_row_tail_sum2<LOG_H, false><<<gi, NTT_THREADS, 0, s_int>>>(ai, T);
         if (af.nsel) k_row_tail_sum2<LOG_H, true><<<gf, NTT_THREADS, 0, s>>>(af, T);
     } else if (waves == 2) {
-        if (ai.nsel) k_row_tail_sum<LOG_H, false, 2><<<gi, NTT_THREADS, 0, s>>>(ai, T);
+        if (ai.nsel) k_row_tail_sum<LOG_H, false, 2><<<gi, NTT_THREADS, 0, s_int>>>(ai, T);
         if (af.nsel) k_row_tail_sum<LOG_H, true, 2><<<gf, NTT_THREADS, 0, s>>>(af, T);
     } else if (waves == 4) {
-        if (ai.nsel) k_row_tail_sum<LOG_H, false, 4><<<gi, NTT_THREADS, 0, s>>>(ai, T);
+        if (ai.nsel) k_row_tail_sum<LOG_H, false, 4><<<gi, NTT_THREADS, 0, s_int>>>(ai, T);
         if (af.nsel) k_row_tail_sum<LOG_H, true, 4><<<gf, NTT_THREADS, 0, s>>>(af, T);
     } else {
-        if (ai.nsel) k_row_tail_sum<LOG_H, false, 3><<<gi, NTT_THREADS, 0, s>>>(ai, T);
+        if (ai.nsel) k_row_tail_sum<LOG_H, false, 3><<<gi, NTT_THREADS, 0, s_int>>>(ai, T);
         if (af.nsel) k_row_tail_sum<LOG_H, true, 3><<<gf, NTT_THREADS, 0, s>>>(af, T);
     }
 }
@@ -1339,6 +1361,7 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
             for (uint32_t c = c0; c < c0 + gcnt; ++c) {
                 const uint32_t lane = c % n_lanes;
                 stream_ = lane_stream[lane];  // the helpers below launch on stream_
+                cur_lane_ = lane;
                 u64 *coef = lane0 + (size_t)lane * w_lane, *dig = coef + w_coef, *pc = dig + w_dig;
                 u64 *til = til0 + (size_t)c * w_til, *conv = conv0 + (size_t)c * w_conv;
                 const u64 *ct = cts + ((size_t)c * n_ct + b0) * ct_words, *evk = evks + (size_t)c * evk_words;
@@ -1351,6 +1374,7 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
                 launch_conv_col(io, tabs_, moddown_conv(nl), lanes());
             }
             stream_ = main;
+            cur_lane_ = 0;
             if (two) {  // the group's sum waits for every lane; the lanes go on with the next group
                 for (uint32_t l = 0; l < n_lanes; ++l) {
                     MK_HIP(hipEventRecord(ev_lane_[l], lane_stream[l]));
@@ -1360,14 +1384,27 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
             SumArgs a{conv0 + (size_t)c0 * w_conv, til0 + (size_t)c0 * w_til,
                       cts + ((size_t)c0 * n_ct + b0) * ct_words, out + (size_t)b0 * ct_words, pinv, pinv + nl,
                       w_conv, w_til, (size_t)n_ct * ct_words, ct_words, gcnt, nl, ext, 2 * cnt, 0, 0, c0 != 0 ? 1u : 0u};
+            // the integer and the fp64 instance of the sum touch disjoint limbs: side by side on two streams
+            const char *sf = std::getenv("MKCKKS_SUM_FORK");
+            const bool sum_fork = two && sf && std::atoi(sf) != 0;  // measured: no gain, off
+            hipStream_t sum_int = sum_stream;
+            if (sum_fork) {
+                sum_int = aux_stream_[0];
+                MK_HIP(hipEventRecord(ev_a_, sum_stream));
+                MK_HIP(hipStreamWaitEvent(sum_int, ev_a_, 0));
+            }
             switch (log_h) {
-                case 9: launch_row3_tail_sum<3>(a, tabs_, sum_stream); break;
+                case 9: launch_row3_tail_sum<3>(a, tabs_, sum_stream, sum_int); break;
                 case 4:
-                    if (three_round_256()) launch_row3_tail_sum<2>(a, tabs_, sum_stream);
-                    else launch_row_tail_sum<4>(a, tabs_, ps_.L, sum_stream);
+                    if (three_round_256()) launch_row3_tail_sum<2>(a, tabs_, sum_stream, sum_int);
+                    else launch_row_tail_sum<4>(a, tabs_, ps_.L, sum_stream, sum_int);
                     break;
-                case 3: launch_row_tail_sum<3>(a, tabs_, ps_.L, sum_stream); break;
-                default: launch_row_tail_sum<2>(a, tabs_, ps_.L, sum_stream); break;
+                case 3: launch_row_tail_sum<3>(a, tabs_, ps_.L, sum_stream, sum_int); break;
+                default: launch_row_tail_sum<2>(a, tabs_, ps_.L, sum_stream, sum_int); break;
+            }
+            if (sum_fork) {
+                MK_HIP(hipEventRecord(ev_b_, sum_int));
+                MK_HIP(hipStreamWaitEvent(sum_stream, ev_b_, 0));
             }
             MK_HIP(hipGetLastError());
         }

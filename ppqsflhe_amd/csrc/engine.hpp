@@ -115,7 +115,7 @@ private:
     const u64 *folded_scale(uint32_t nl);
     const u64 *p_inverse(uint32_t nl);
     void modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, uint32_t cnt, uint32_t nl,
-                    bool rows_int_only = false);
+                    bool rows_int_only = false, hipEvent_t conv_done = nullptr);
     void keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u64 *coef, u64 *dig, u64 *til, uint32_t cnt,
                           uint32_t nl);
     void moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t out_stride, const u64 *add,
@@ -135,6 +135,10 @@ private:
     static constexpr int MAX_SUM_LANES = 4;  // client lanes of reencrypt_sum: main, side_stream_, extra_lane_[0..1]
     hipStream_t extra_lane_[MAX_SUM_LANES - 2] = {nullptr, nullptr};
     hipEvent_t ev_lane_[MAX_SUM_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    // per client lane: the fp64 fused inner product runs beside the integer row pass + inner product (independent limbs)
+    hipStream_t aux_stream_[MAX_SUM_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_conv_[MAX_SUM_LANES] = {nullptr, nullptr, nullptr, nullptr}, ev_aux_[MAX_SUM_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t cur_lane_ = 0;
     bool two_lanes_ = false;
     uint32_t *d_rot_ = nullptr;
     void *d_ksi_ = nullptr;

@@ -1065,7 +1065,7 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
         // (rows_int_only: the fp64 limbs finish their transform inside the fused inner-product kernel, which may
         // start as soon as the conversions are done: conv_done)
         if (conv_done) MK_HIP(hipEventRecord(conv_done, stream_));
-        launch_row<false>(row, tabs_, cnt * nparts, TailArgs{}, lanes(), rows_int_only ? 1u : 3u);
+        if (!skip_rows_) launch_row<false>(row, tabs_, cnt * nparts, TailArgs{}, lanes(), rows_int_only ? 1u : 3u);
         MK_HIP(hipGetLastError());
         return;
     }
@@ -1201,6 +1201,21 @@ static void launch_row3_inner_fp_n(const InnerArgs &a, const NttTables &T, uint3
     }
 }
 
+template <int LOGC>
+static void launch_row3_inner_int_n(const InnerArgs &a, const NttTables &T, uint32_t nparts, uint32_t L, hipStream_t s) {
+    if (!a.nsel) return;
+    const dim3 grid(((1u << T.log_r1) / RowT<LOGC>::ROWS) * a.nsel * a.items);
+    switch (nparts) {
+        case 1: k_row3_inner_int<1, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T, L); break;
+        case 2: k_row3_inner_int<2, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T, L); break;
+        case 3: k_row3_inner_int<3, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T, L); break;
+        case 4: k_row3_inner_int<4, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T, L); break;
+        case 5: k_row3_inner_int<5, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T, L); break;
+        case 6: k_row3_inner_int<6, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T, L); break;
+        default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
+    }
+}
+
 // S1-S4 of the hybrid key switch for `cnt` ciphertexts: ModUp digits of c1 (EvalKeySwitchPrecomputeCore) and their
 // inner product with the eval key over Q_l P (EvalFastKeySwitchCoreExt) -> til [cnt][2][ext][N].
 // With the radix kernels the fp64 Q limbs finish their forward transform inside k_row_inner_fp (digits stay on chip);
@@ -1219,7 +1234,11 @@ void Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u
     const char *fk = std::getenv("MKCKKS_INNER_FORK");
     const bool fork = fuse && aux_stream_[0] != nullptr && fk && std::atoi(fk) != 0;  // measured: -2.7 %, off
     const uint32_t lane = cur_lane_ < MAX_SUM_LANES ? cur_lane_ : 0;
+    const char *fi = std::getenv("MKCKKS_FUSE_INNER_INT");
+    const bool fuse_int = fuse && (row_h == 4 || row_h == 9) && (!fi || std::atoi(fi) != 0);  // +1.3 % at C3
+    skip_rows_ = fuse_int;  // no separate row pass at all: both classes finish inside the fused kernels
     modup_core(c1, ct_stride, coef, dig, cnt, nl, fuse, fork ? ev_conv_[lane] : nullptr);
+    skip_rows_ = false;
     if (fuse) {
         // the fused fp64 kernel and the integer row pass + inner product touch disjoint limbs: side by side
         hipStream_t fs = stream_;
@@ -1236,6 +1255,14 @@ void Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u
         if (fork) MK_HIP(hipEventRecord(ev_aux_[lane], fs));
     }
     const unsigned long long mask = fuse ? (all_mask & ~fp_mask) : all_mask;
+    if (fuse_int) {  // integer limbs: row pass + inner product in one three-round kernel as well
+        InnerArgs a{dig, c1, evk, til, ct_stride, nl, ext, D, ps_.alpha, cnt, mask, (uint32_t)__builtin_popcountll(mask)};
+        if (row_h == 9) launch_row3_inner_int_n<3>(a, tabs_, nparts, ps_.L, stream_);
+        else launch_row3_inner_int_n<2>(a, tabs_, nparts, ps_.L, stream_);
+        if (fork) MK_HIP(hipStreamWaitEvent(stream_, ev_aux_[lane], 0));
+        MK_HIP(hipGetLastError());
+        return;
+    }
     EwGeom g{n, nl, ps_.L};
     switch (nparts) {
         case 1: launch_inner<1>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, mask, stream_); break;

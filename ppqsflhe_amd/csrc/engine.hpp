@@ -139,6 +139,7 @@ private:
     hipStream_t aux_stream_[MAX_SUM_LANES] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_conv_[MAX_SUM_LANES] = {nullptr, nullptr, nullptr, nullptr}, ev_aux_[MAX_SUM_LANES] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t cur_lane_ = 0;
+    bool skip_rows_ = false;  // modup_core: leave the row pass of the converted digits to the fused kernels
     bool two_lanes_ = false;
     uint32_t *d_rot_ = nullptr;
     void *d_ksi_ = nullptr;

@@ -1379,4 +1379,120 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, N
     }
 }
 
+// The same fusion for the INTEGER limbs (q0 and the P limbs): forward row pass of every converted digit + eval-key
+// inner product with 128-bit accumulators (one Barrett at the end), three-round geometry (8 words per thread keep the
+// 16 accumulator words + data + twiddles within 3 waves per SIMD).  a.slot_mask selects SLOTS (q0 = slot 0, P limbs =
+// slots nl..ext-1); P limbs have no owning digit.
+template <int NPARTS, int LOGC>
+__global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_int(InnerArgs a, NttTables T, uint32_t L) {
+    using TL = RowT<LOGC>;
+    constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
+    __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
+    Row3Ctx c;
+    c.lds = lds;
+    c.twa = lds + TL::WORDS;
+    c.twa_sh = c.twa + TL::TWA;
+    c.twb = c.twa_sh + TL::TWA;
+    c.twb_sh = c.twb + TL::TWB;
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
+    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
+    uint32_t grp, item;
+    if (groups % 8 == 0) {
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / a.items) * 8 + xcd;
+        item = qidx % a.items;
+    } else {
+        grp = blockIdx.x / a.items;
+        item = blockIdx.x % a.items;
+    }
+    const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);
+    const uint32_t id = limb_id_of(sl, a.nl, L);
+    const LimbConst lc = T.limb[id];
+    const int own = sl < a.nl ? (int)(sl / a.alpha) : -1;
+    const uint32_t row0 = (grp % tiles) * S;
+    c.g = threadIdx.x / TPR;
+    c.t = threadIdx.x % TPR;
+    const u64 *tw = T.tw + (size_t)id * n, *tw_sh = T.tw_sh + (size_t)id * n;
+    row3_stage_twiddles<LOGC>(c, tw, tw_sh, r1 + row0);
+    u64 wc[7], wpc[7];
+    row3_load_c_twiddles<LOGC>(tw, tw_sh, r1 + row0 + c.g, c.t, wc, wpc);
+    const size_t tile_off = (size_t)row0 * R;
+    int jn = own == 0 ? 1 : 0;
+    const u64 *dig0 = a.dig + ((size_t)item * NPARTS * a.ext + sl) * n + tile_off + (size_t)c.g * R + c.t;
+    u64 x[8];
+    if (jn < NPARTS) {
+        const u64 *src = dig0 + (size_t)jn * a.ext * n;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + TPR * k);
+    }
+    u64 h0[2 * PAIRS], l0[2 * PAIRS], h1[2 * PAIRS], l1[2 * PAIRS];
+#pragma unroll
+    for (int i = 0; i < 2 * PAIRS; ++i) h0[i] = l0[i] = h1[i] = l1[i] = 0;
+    if (own >= 0) {  // the digit that owns this limb: c1 itself
+        const u64 *y0 = a.c1 + (size_t)item * a.c1_stride + (size_t)sl * n + tile_off;
+        const u64 *e0 = a.evk + (((size_t)own * 2 + 0) * a.D + id) * n + tile_off;
+        const u64 *e1 = a.evk + (((size_t)own * 2 + 1) * a.D + id) * n + tile_off;
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = row3_pair<LOGC>(c.g, c.t, i);
+            const ulong2 yy = ld_stream2(reinterpret_cast<const ulong2 *>(y0) + e);
+            const ulong2 b = reinterpret_cast<const ulong2 *>(e0)[e];
+            const ulong2 cc = reinterpret_cast<const ulong2 *>(e1)[e];
+            mac128(h0[2 * i], l0[2 * i], yy.x, b.x);
+            mac128(h0[2 * i + 1], l0[2 * i + 1], yy.y, b.y);
+            mac128(h1[2 * i], l1[2 * i], yy.x, cc.x);
+            mac128(h1[2 * i + 1], l1[2 * i + 1], yy.y, cc.y);
+        }
+    }
+    __syncthreads();  // twiddles staged
+#pragma unroll 1
+    for (int dj = jn; dj < NPARTS; dj = jn) {
+        jn = dj + 1 == own ? dj + 2 : dj + 1;
+        wave_lds_sync();
+        row3_forward<false, LOGC>(x, c, wc, wpc, lc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 8 * c.t + k)] = canon8(x[k], lc.q, lc.q2);
+        if (jn < NPARTS) {
+            const u64 *src = dig0 + (size_t)jn * a.ext * n;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + TPR * k);
+        }
+        wave_lds_sync();
+        const u64 *e0 = a.evk + (((size_t)dj * 2 + 0) * a.D + id) * n + tile_off;
+        const u64 *e1 = a.evk + (((size_t)dj * 2 + 1) * a.D + id) * n + tile_off;
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = row3_pair<LOGC>(c.g, c.t, i);
+            const int xx = (2 * e) % R;
+            const ulong2 b = reinterpret_cast<const ulong2 *>(e0)[e];
+            const ulong2 cc = reinterpret_cast<const ulong2 *>(e1)[e];
+            const u64 yx = lds[TL::at(c.g, xx)], yz = lds[TL::at(c.g, xx + 1)];
+            mac128(h0[2 * i], l0[2 * i], yx, b.x);
+            mac128(h0[2 * i + 1], l0[2 * i + 1], yz, b.y);
+            mac128(h1[2 * i], l1[2 * i], yx, cc.x);
+            mac128(h1[2 * i + 1], l1[2 * i + 1], yz, cc.y);
+        }
+    }
+    u64 *t0 = a.til + (((size_t)item * 2 + 0) * a.ext + sl) * n + tile_off;
+    u64 *t1 = a.til + (((size_t)item * 2 + 1) * a.ext + sl) * n + tile_off;
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+        const int e = row3_pair<LOGC>(c.g, c.t, i);
+        ulong2 r0, r1v;
+        if (NPARTS <= 4) {
+            r0.x = reduce_sum4(h0[2 * i], l0[2 * i], lc);
+            r0.y = reduce_sum4(h0[2 * i + 1], l0[2 * i + 1], lc);
+            r1v.x = reduce_sum4(h1[2 * i], l1[2 * i], lc);
+            r1v.y = reduce_sum4(h1[2 * i + 1], l1[2 * i + 1], lc);
+        } else {
+            r0.x = reduce_wide(h0[2 * i], l0[2 * i], lc);
+            r0.y = reduce_wide(h0[2 * i + 1], l0[2 * i + 1], lc);
+            r1v.x = reduce_wide(h1[2 * i], l1[2 * i], lc);
+            r1v.y = reduce_wide(h1[2 * i + 1], l1[2 * i + 1], lc);
+        }
+        st_stream2(reinterpret_cast<ulong2 *>(t0) + e, r0);
+        st_stream2(reinterpret_cast<ulong2 *>(t1) + e, r1v);
+    }
+}
+
 }  // namespace mk

@@ -1086,16 +1086,31 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
     }
 }
 
+// INTT of the P limbs (til -> pc); with rows_done the inverse row pass already happened inside the fused inner-product
+// kernel and only the (scaling, packing) inverse column pass remains, in place on pc
+void Engine::inverse_p_limbs(const NttIo &s5, uint32_t cnt, const u64 *scale, const u64 *scale_sh, int pack, bool rows_done) {
+    if (!rows_done) {
+        ntt_passes(s5, tabs_, cnt, true, scale, scale_sh, lanes(), pack);
+        return;
+    }
+    NttIo second = s5;
+    second.in = s5.out;
+    second.in_stride = s5.out_stride;
+    second.in_slot0 = s5.out_slot0;
+    launch_col<true>(second, tabs_, cnt, scale, scale_sh, lanes(), pack);
+    MK_HIP(hipGetLastError());
+}
+
 // ApproxModDown on `cnt` polynomials til[item][ext][N] -> out[item] (items out_stride apart, nl limbs each);
 // add (optional): ciphertext array whose c0 is added on even items (KeySwitchInPlace: c0 += ...).
 void Engine::moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t out_stride, const u64 *add,
-                          size_t add_stride, uint32_t cnt, uint32_t nl, bool accumulate) {
+                          size_t add_stride, uint32_t cnt, uint32_t nl, bool accumulate, bool p_rows_done) {
     const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, D = ps_.D;
     const u64 *fold = folded_scale(nl), *pinv = p_inverse(nl);
     const bool conv_fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0;  // conversion inside the column pass
     const bool tail_fused = conv_fused && row_tail_supported(tabs_);               // tail inside the row pass
     NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
-    ntt_passes(s5, tabs_, cnt, true, fold, fold + D, lanes(), conv_fused ? 1 : 0);
+    inverse_p_limbs(s5, cnt, fold, fold + D, conv_fused ? 1 : 0, p_rows_done);
     const DevConv &cv = moddown_conv(nl);
     ConvIo io{pc, conv, (size_t)K * n, (size_t)nl * n, cnt, 0, 0};
     EwGeom g{n, nl, ps_.L};
@@ -1201,26 +1216,45 @@ static void launch_row3_inner_fp_n(const InnerArgs &a, const NttTables &T, uint3
     }
 }
 
-template <int LOGC>
-static void launch_row3_inner_int_n(const InnerArgs &a, const NttTables &T, uint32_t nparts, uint32_t L, hipStream_t s) {
+template <int LOGC, bool INVP>
+static void launch_row3_inner_int_k(const InnerArgs &a, const NttTables &T, uint32_t nparts, uint32_t L, u64 *pc,
+                                    uint32_t K, hipStream_t s) {
     if (!a.nsel) return;
     const dim3 grid(((1u << T.log_r1) / RowT<LOGC>::ROWS) * a.nsel * a.items);
     switch (nparts) {
-        case 1: k_row3_inner_int<1, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T, L); break;
-        case 2: k_row3_inner_int<2, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T, L); break;
-        case 3: k_row3_inner_int<3, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T, L); break;
-        case 4: k_row3_inner_int<4, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T, L); break;
-        case 5: k_row3_inner_int<5, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T, L); break;
-        case 6: k_row3_inner_int<6, LOGC><<<grid, NTT_THREADS, 0, s>>>(a, T, L); break;
+        case 1: k_row3_inner_int<1, LOGC, INVP><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); break;
+        case 2: k_row3_inner_int<2, LOGC, INVP><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); break;
+        case 3: k_row3_inner_int<3, LOGC, INVP><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); break;
+        case 4: k_row3_inner_int<4, LOGC, INVP><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); break;
+        case 5: k_row3_inner_int<5, LOGC, INVP><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); break;
+        case 6: k_row3_inner_int<6, LOGC, INVP><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); break;
         default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
     }
+}
+// integer slots of the extended basis: Q slots (q0) keep their accumulators in til; P slots continue into the inverse
+// row pass when `pc` is given (its own kernel instance: different epilogue, different register budget)
+template <int LOGC>
+static void launch_row3_inner_int_n(const InnerArgs &a, const NttTables &T, uint32_t nparts, uint32_t L, u64 *pc,
+                                    uint32_t K, hipStream_t s) {
+    if (!pc) {
+        launch_row3_inner_int_k<LOGC, false>(a, T, nparts, L, nullptr, K, s);
+        return;
+    }
+    const unsigned long long q_slots = a.nl >= 64 ? ~0ull : ((1ull << a.nl) - 1);
+    InnerArgs aq = a, ap = a;
+    aq.slot_mask = a.slot_mask & q_slots;
+    ap.slot_mask = a.slot_mask & ~q_slots;
+    aq.nsel = (uint32_t)__builtin_popcountll(aq.slot_mask);
+    ap.nsel = (uint32_t)__builtin_popcountll(ap.slot_mask);
+    launch_row3_inner_int_k<LOGC, true>(ap, T, nparts, L, pc, K, s);
+    launch_row3_inner_int_k<LOGC, false>(aq, T, nparts, L, nullptr, K, s);
 }
 
 // S1-S4 of the hybrid key switch for `cnt` ciphertexts: ModUp digits of c1 (EvalKeySwitchPrecomputeCore) and their
 // inner product with the eval key over Q_l P (EvalFastKeySwitchCoreExt) -> til [cnt][2][ext][N].
 // With the radix kernels the fp64 Q limbs finish their forward transform inside k_row_inner_fp (digits stay on chip);
 // integer limbs (q0, P) take the row pass + k_inner_product_b, which keeps the eval key in registers across the batch.
-void Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u64 *coef, u64 *dig, u64 *til,
+bool Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u64 *coef, u64 *dig, u64 *til, u64 *pc,
                               uint32_t cnt, uint32_t nl) {
     const uint32_t n = ps_.n, ext = nl + ps_.K, nparts = ps_.num_parts(nl), D = ps_.D;
     const char *fe = std::getenv("MKCKKS_FUSE_INNER");  // read per call: the tests run both paths in one process
@@ -1257,11 +1291,13 @@ void Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u
     const unsigned long long mask = fuse ? (all_mask & ~fp_mask) : all_mask;
     if (fuse_int) {  // integer limbs: row pass + inner product in one three-round kernel as well
         InnerArgs a{dig, c1, evk, til, ct_stride, nl, ext, D, ps_.alpha, cnt, mask, (uint32_t)__builtin_popcountll(mask)};
-        if (row_h == 9) launch_row3_inner_int_n<3>(a, tabs_, nparts, ps_.L, stream_);
-        else launch_row3_inner_int_n<2>(a, tabs_, nparts, ps_.L, stream_);
+        const char *pi = std::getenv("MKCKKS_FUSE_P_INVERSE");
+        u64 *pc_fused = (pc && (!pi || std::atoi(pi) != 0)) ? pc : nullptr;
+        if (row_h == 9) launch_row3_inner_int_n<3>(a, tabs_, nparts, ps_.L, pc_fused, ps_.K, stream_);
+        else launch_row3_inner_int_n<2>(a, tabs_, nparts, ps_.L, pc_fused, ps_.K, stream_);
         if (fork) MK_HIP(hipStreamWaitEvent(stream_, ev_aux_[lane], 0));
         MK_HIP(hipGetLastError());
-        return;
+        return pc_fused != nullptr;
     }
     EwGeom g{n, nl, ps_.L};
     switch (nparts) {
@@ -1275,6 +1311,7 @@ void Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u
     }
     if (fork) MK_HIP(hipStreamWaitEvent(stream_, ev_aux_[lane], 0));
     MK_HIP(hipGetLastError());
+    return false;
 }
 
 void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t cnt, uint32_t nl, bool accumulate) {
@@ -1287,9 +1324,9 @@ void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t c
     const u64 *c1 = ct + (size_t)nl * n;  // component 1 of item 0; items are ct_stride apart
 
     // S1-S4: ModUp digits of c1 and their inner product with the eval key
-    keyswitch_digits(c1, ct_stride, evk, coef, dig, til, cnt, nl);
+    const bool p_rows = keyswitch_digits(c1, ct_stride, evk, coef, dig, til, pc, cnt, nl);
     // S5: ApproxModDown of both components (2*cnt polynomials of ext limbs), + c0 on component 0
-    moddown_core(til, pc, conv, out, (size_t)nl * n, ct, ct_stride, 2 * cnt, nl, accumulate);
+    moddown_core(til, pc, conv, out, (size_t)nl * n, ct, ct_stride, 2 * cnt, nl, accumulate, p_rows);
 }
 
 template <int LOGC>
@@ -1393,10 +1430,10 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
                 u64 *til = til0 + (size_t)c * w_til, *conv = conv0 + (size_t)c * w_conv;
                 const u64 *ct = cts + ((size_t)c * n_ct + b0) * ct_words, *evk = evks + (size_t)c * evk_words;
                 const u64 *c1 = ct + (size_t)nl * n;
-                keyswitch_digits(c1, ct_words, evk, coef, dig, til, cnt, nl);
+                const bool p_rows = keyswitch_digits(c1, ct_words, evk, coef, dig, til, pc, cnt, nl);
                 // ModDown up to the column pass of the converted limbs
                 NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
-                ntt_passes(s5, tabs_, 2 * cnt, true, fold, fold + D, lanes(), 1);
+                inverse_p_limbs(s5, 2 * cnt, fold, fold + D, 1, p_rows);
                 ConvIo io{pc, conv, (size_t)K * n, (size_t)nl * n, 2 * cnt, 0, 0};
                 launch_conv_col(io, tabs_, moddown_conv(nl), lanes());
             }

@@ -116,10 +116,13 @@ private:
     const u64 *p_inverse(uint32_t nl);
     void modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, uint32_t cnt, uint32_t nl,
                     bool rows_int_only = false, hipEvent_t conv_done = nullptr);
-    void keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u64 *coef, u64 *dig, u64 *til, uint32_t cnt,
-                          uint32_t nl);
+    // returns true when the inverse ROW pass of the P limbs was done on the fly into `pc` (ModDown then starts with
+    // the inverse column pass)
+    bool keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u64 *coef, u64 *dig, u64 *til, u64 *pc,
+                          uint32_t cnt, uint32_t nl);
     void moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t out_stride, const u64 *add,
-                      size_t add_stride, uint32_t cnt, uint32_t nl, bool accumulate);
+                      size_t add_stride, uint32_t cnt, uint32_t nl, bool accumulate, bool p_rows_done = false);
+    void inverse_p_limbs(const struct NttIo &s5, uint32_t cnt, const u64 *scale, const u64 *scale_sh, int pack, bool rows_done);
 
     ParamSet ps_;
     int device_ = -1;

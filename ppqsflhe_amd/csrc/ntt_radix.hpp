@@ -1379,12 +1379,69 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, N
     }
 }
 
+// inverse ROW pass of this thread's row (integer limbs): x[k] = word 8 t + k on entry (values in [0,2q)), on exit
+// x[k] = word t + TPR k in [0,2q) -- what k_ntt_row_r<INV> hands to the inverse column pass.  c.twa / c.twb hold the
+// INVERSE tables' round-A / round-B twiddles, wc / wpc the thread's inverse round-C twiddles.
+template <int LOGC>
+MK_D void row3_inverse_int(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], const u64 (&wpc)[7], const LimbConst &lc) {
+    using TL = RowT<LOGC>;
+    constexpr int S = TL::ROWS, TPR = TL::TPR, C = TL::C;
+    const int a = c.t / C, cc = c.t % C;
+    if (LOGC == 3) {
+        radix_inverse_any<3, false>(x, wc, wpc, lc);
+    } else {
+        u64 y0[4] = {x[0], x[1], x[2], x[3]}, y1[4] = {x[4], x[5], x[6], x[7]};
+        const u64 w0[3] = {wc[0], wc[1], wc[2]}, wp0[3] = {wpc[0], wpc[1], wpc[2]};
+        const u64 w1[3] = {wc[3], wc[4], wc[5]}, wp1[3] = {wpc[3], wpc[4], wpc[5]};
+        radix_inverse_any<2, false>(y0, w0, wp0, lc);
+        radix_inverse_any<2, false>(y1, w1, wp1, lc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            x[k] = y0[k];
+            x[4 + k] = y1[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c.lds[TL::at(c.g, 8 * c.t + k)] = x[k];
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = c.lds[TL::at(c.g, 8 * C * a + C * k + cc)];
+    u64 w[7], wp[7];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int gg = 0; gg < (1 << s); ++gg) {
+            const int e = S * 8 * ((1 << s) - 1) + ((c.g * 8 + a) << s) + gg;
+            w[(1 << s) - 1 + gg] = c.twb[e];
+            wp[(1 << s) - 1 + gg] = c.twb_sh[e];
+        }
+    radix_inverse_any<3, false>(x, w, wp, lc);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c.lds[TL::at(c.g, 8 * C * a + C * k + cc)] = x[k];
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = c.lds[TL::at(c.g, c.t + TPR * k)];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int gg = 0; gg < (1 << s); ++gg) {
+            const int e = S * ((1 << s) - 1) + (c.g << s) + gg;
+            w[(1 << s) - 1 + gg] = c.twa[e];
+            wp[(1 << s) - 1 + gg] = c.twa_sh[e];
+        }
+    radix_inverse_any<3, false>(x, w, wp, lc);
+}
+
 // The same fusion for the INTEGER limbs (q0 and the P limbs): forward row pass of every converted digit + eval-key
 // inner product with 128-bit accumulators (one Barrett at the end), three-round geometry (8 words per thread keep the
 // 16 accumulator words + data + twiddles within 3 waves per SIMD).  a.slot_mask selects SLOTS (q0 = slot 0, P limbs =
 // slots nl..ext-1); P limbs have no owning digit.
-template <int NPARTS, int LOGC>
-__global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_int(InnerArgs a, NttTables T, uint32_t L) {
+#ifndef MK_INVP_WAVES
+#define MK_INVP_WAVES 2  // 168 VGPRs would spill 19 registers in the P instance; 2 waves measured +0.7 %
+#endif
+template <int NPARTS, int LOGC, bool INVP>
+__global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_inner_int(InnerArgs a, NttTables T, uint32_t L, u64 *pc,
+                                                                   uint32_t K) {
     using TL = RowT<LOGC>;
     constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
     __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
@@ -1473,25 +1530,47 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_int(InnerArgs a, 
             mac128(h1[2 * i + 1], l1[2 * i + 1], yz, cc.y);
         }
     }
-    u64 *t0 = a.til + (((size_t)item * 2 + 0) * a.ext + sl) * n + tile_off;
-    u64 *t1 = a.til + (((size_t)item * 2 + 1) * a.ext + sl) * n + tile_off;
+    // P limbs with `pc` given: the results go straight through the INVERSE row pass (first pass of ApproxModDown's
+    // SetFormat(COEFFICIENT)) and land in pc[2 item + comp][K][N]; the accumulators over P never reach HBM
+    constexpr bool inv = INVP;  // this instance is launched over P slots only, with pc given
+    const u64 *itw = T.itw + (size_t)id * n, *itw_sh = T.itw_sh + (size_t)id * n;
+    if (inv) {
+        __syncthreads();  // every wave is done with the forward round-A/B twiddles
+        row3_stage_twiddles<LOGC>(c, itw, itw_sh, r1 + row0);
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int comp = 0; comp < 2; ++comp) {
+        ulong2 res[PAIRS];
 #pragma unroll
-    for (int i = 0; i < PAIRS; ++i) {
-        const int e = row3_pair<LOGC>(c.g, c.t, i);
-        ulong2 r0, r1v;
-        if (NPARTS <= 4) {
-            r0.x = reduce_sum4(h0[2 * i], l0[2 * i], lc);
-            r0.y = reduce_sum4(h0[2 * i + 1], l0[2 * i + 1], lc);
-            r1v.x = reduce_sum4(h1[2 * i], l1[2 * i], lc);
-            r1v.y = reduce_sum4(h1[2 * i + 1], l1[2 * i + 1], lc);
-        } else {
-            r0.x = reduce_wide(h0[2 * i], l0[2 * i], lc);
-            r0.y = reduce_wide(h0[2 * i + 1], l0[2 * i + 1], lc);
-            r1v.x = reduce_wide(h1[2 * i], l1[2 * i], lc);
-            r1v.y = reduce_wide(h1[2 * i + 1], l1[2 * i + 1], lc);
+        for (int i = 0; i < PAIRS; ++i) {
+            const u64 hx = comp ? h1[2 * i] : h0[2 * i], lx = comp ? l1[2 * i] : l0[2 * i];
+            const u64 hy = comp ? h1[2 * i + 1] : h0[2 * i + 1], ly = comp ? l1[2 * i + 1] : l0[2 * i + 1];
+            res[i].x = NPARTS <= 4 ? reduce_sum4(hx, lx, lc) : reduce_wide(hx, lx, lc);
+            res[i].y = NPARTS <= 4 ? reduce_sum4(hy, ly, lc) : reduce_wide(hy, ly, lc);
         }
-        st_stream2(reinterpret_cast<ulong2 *>(t0) + e, r0);
-        st_stream2(reinterpret_cast<ulong2 *>(t1) + e, r1v);
+        if (!inv) {
+            u64 *td = a.til + (((size_t)item * 2 + comp) * a.ext + sl) * n + tile_off;
+#pragma unroll
+            for (int i = 0; i < PAIRS; ++i) st_stream2(reinterpret_cast<ulong2 *>(td) + row3_pair<LOGC>(c.g, c.t, i), res[i]);
+        } else {
+            wave_lds_sync();  // the previous use of this wave's row (last digit's products / component 0) is over
+#pragma unroll
+            for (int i = 0; i < PAIRS; ++i) {
+                const int xx = (2 * row3_pair<LOGC>(c.g, c.t, i)) % R;
+                lds[TL::at(c.g, xx)] = res[i].x;
+                lds[TL::at(c.g, xx + 1)] = res[i].y;
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = lds[TL::at(c.g, 8 * c.t + k)];
+            u64 iwc[7], iwpc[7];  // (re)loaded per component: keeps them out of the accumulators' live range
+            row3_load_c_twiddles<LOGC>(itw, itw_sh, r1 + row0 + c.g, c.t, iwc, iwpc);
+            row3_inverse_int<LOGC>(x, c, iwc, iwpc, lc);
+            u64 *pd = pc + (((size_t)item * 2 + comp) * K + (sl - a.nl)) * n + tile_off + (size_t)c.g * R + c.t;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) st_pass(pd + TPR * k, x[k]);  // lazy [0,2q): the inverse column pass scales
+        }
     }
 }
 

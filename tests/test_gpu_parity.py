@@ -380,7 +380,8 @@ def test_reencrypt_sum(ctxs, name, nl, C, B):
 @pytest.mark.parametrize("env", [{"MKCKKS_FUSE_INNER": "0"}, {"MKCKKS_SUM_PAIR": "0"},
                                  {"MKCKKS_FUSE_INNER": "0", "MKCKKS_SUM_PAIR": "0"},
                                  {"MKCKKS_ROW3X": "1"}, {"MKCKKS_ROW3X": "0"},  # three-round vs two-round 256-point kernels
-                                 {"MKCKKS_FUSE_INNER_INT": "0"}])  # integer limbs: separate row pass + inner product
+                                 {"MKCKKS_FUSE_INNER_INT": "0"},  # integer limbs: separate row pass + inner product
+                                 {"MKCKKS_FUSE_P_INVERSE": "0"}])  # P limbs: accumulators to HBM, separate inverse row pass
 def test_unfused_kernel_paths_stay_bit_exact(ctxs, monkeypatch, env):
     """The separate row pass + inner product and the one-client-per-iteration sum kernel remain in the library (other
     ring sizes, switches for A/B measurements): same bits as the fused default and as the oracle at N = 2^16."""

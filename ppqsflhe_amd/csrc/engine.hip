@@ -1270,9 +1270,14 @@ bool Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u
     const uint32_t lane = cur_lane_ < MAX_SUM_LANES ? cur_lane_ : 0;
     const char *fi = std::getenv("MKCKKS_FUSE_INNER_INT");
     const bool fuse_int = fuse && (row_h == 4 || row_h == 9) && (!fi || std::atoi(fi) != 0);  // +1.3 % at C3
-    skip_rows_ = fuse_int;  // no separate row pass at all: both classes finish inside the fused kernels
-    modup_core(c1, ct_stride, coef, dig, cnt, nl, fuse, fork ? ev_conv_[lane] : nullptr);
-    skip_rows_ = false;
+    {
+        struct Reset {  // cleared on every exit path: the public ModUp entry point must never inherit it
+            bool &flag;
+            ~Reset() { flag = false; }
+        } reset{skip_rows_};
+        skip_rows_ = fuse_int;  // no separate row pass at all: both classes finish inside the fused kernels
+        modup_core(c1, ct_stride, coef, dig, cnt, nl, fuse, fork ? ev_conv_[lane] : nullptr);
+    }
     if (fuse) {
         // the fused fp64 kernel and the integer row pass + inner product touch disjoint limbs: side by side
         hipStream_t fs = stream_;

@@ -406,6 +406,34 @@ def test_unfused_kernel_paths_stay_bit_exact(ctxs, monkeypatch, env):
     assert np.array_equal(d_one.to_host()[0], o.reencrypt(cts[0, 0], evks[0]))
 
 
+def test_fused_path_across_workspace_chunks(ctxs, monkeypatch):
+    """N = 2^16 with a workspace chunk of 2 ciphertexts: 3 ciphertexts per client take one full and one partial chunk
+    through the fused kernels (reencrypt_sum with two client lanes, and the single-client reencrypt)."""
+    from ppqsflhe_amd import Context
+    _, o = ctxs("c3")
+    a = CONFIGS["c3"]
+    monkeypatch.setenv("MKCKKS_CHUNK", "2")
+    g = Context(a[0], a[1], a[2], a[3], dnum=a[4], device=0)
+    try:
+        nl, C, B = 12, 2, 3
+        rng = np.random.default_rng(5)
+        cts = np.stack([rand_ct(rng, g, nl, B) for _ in range(C)])
+        evks = np.stack([rand_polys(rng, g, list(range(g.D)) * (2 * g.beta), 1).reshape(g.beta, 2, g.D, g.N)
+                         for _ in range(C)])
+        d_out = g.empty((B, 2, nl, g.N))
+        g.reencrypt_sum(g.to_device(cts), g.to_device(evks), d_out, C, B, nl)
+        got = d_out.to_host()
+        d_one = g.empty((B, 2, nl, g.N))
+        g.reencrypt(g.to_device(cts[1]), g.to_device(evks[1]), d_one, B, nl)
+        one = d_one.to_host()
+        for b in (0, 2):  # first ciphertext of the full chunk, the lone ciphertext of the partial one
+            r0, r1 = o.reencrypt(cts[0, b], evks[0]), o.reencrypt(cts[1, b], evks[1])
+            assert np.array_equal(one[b], r1)
+            assert np.array_equal(got[b], o.eval_add(r0, r1))
+    finally:
+        g.close()
+
+
 def test_device_samplers(ctxs):
     """Philox samplers in HBM: distributional checks (OpenFHE's PRNG stream is not reproducible), determinism per
     (seed, stream), independence across streams, exact range of the uniform limbs."""

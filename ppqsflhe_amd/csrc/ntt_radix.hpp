@@ -28,7 +28,10 @@ namespace mk {
 
 // streaming (read-once / write-once) accesses: non-temporal (MK_NT in modarith.hpp: 1 = fused row kernels, 2 = every
 // transform pass; data re-read from L2 by other workgroups -- twiddles, eval-key tiles, conversion sources -- stay default)
-MK_D u64 ld_stream(const u64 *p) { return MK_NT ? __builtin_nontemporal_load(p) : *p; }
+#ifndef MK_NT8
+#define MK_NT8 0  // 8-byte (strided) loads stay on the default path: as non-temporal they cost 1.4 % (same-box A/B)
+#endif
+MK_D u64 ld_stream(const u64 *p) { return (MK_NT && MK_NT8) ? __builtin_nontemporal_load(p) : *p; }
 MK_D ulong2 ld_stream2(const ulong2 *p) {
     if (MK_NT) {
         ulong2 v;
@@ -38,7 +41,7 @@ MK_D ulong2 ld_stream2(const ulong2 *p) {
     }
     return *p;
 }
-MK_D u64 ld_pass(const u64 *p) { return MK_NT >= 2 ? __builtin_nontemporal_load(p) : *p; }
+MK_D u64 ld_pass(const u64 *p) { return (MK_NT >= 2 && MK_NT8) ? __builtin_nontemporal_load(p) : *p; }
 MK_D void st_pass(u64 *p, u64 v) {
     if (MK_NT >= 2) __builtin_nontemporal_store(v, p);
     else *p = v;

@@ -42,8 +42,11 @@ MK_D ulong2 ld_stream2(const ulong2 *p) {
     return *p;
 }
 MK_D u64 ld_pass(const u64 *p) { return (MK_NT >= 2 && MK_NT8) ? __builtin_nontemporal_load(p) : *p; }
+#ifndef MK_NT8S
+#define MK_NT8S 1  // 8-byte strided STORES do profit from the non-temporal policy (+2.5 % against plain stores)
+#endif
 MK_D void st_pass(u64 *p, u64 v) {
-    if (MK_NT >= 2) __builtin_nontemporal_store(v, p);
+    if (MK_NT >= 2 && MK_NT8S) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 MK_D ulong2 ld_pass2(const ulong2 *p) {

@@ -434,6 +434,24 @@ def test_fused_path_across_workspace_chunks(ctxs, monkeypatch):
         g.close()
 
 
+def test_fused_kernels_are_deterministic(ctxs):
+    """The row kernels synchronise LDS hand-offs at wave level only (no workgroup barrier): 25 repetitions of the fused
+    N = 2^16 path on the same inputs, with other work in flight on the device, must give identical bits every time."""
+    g, _ = ctxs("c3")
+    nl, C, B = 12, 4, 4
+    rng = np.random.default_rng(99)
+    cts = np.stack([rand_ct(rng, g, nl, B) for _ in range(C)])
+    evks = np.stack([rand_polys(rng, g, list(range(g.D)) * (2 * g.beta), 1).reshape(g.beta, 2, g.D, g.N)
+                     for _ in range(C)])
+    d_cts, d_evks = g.to_device(cts), g.to_device(evks)
+    d_out = g.empty((B, 2, nl, g.N))
+    g.reencrypt_sum(d_cts, d_evks, d_out, C, B, nl)
+    want = d_out.to_host()
+    for _ in range(25):
+        g.reencrypt_sum(d_cts, d_evks, d_out, C, B, nl)
+        assert np.array_equal(d_out.to_host(), want)
+
+
 def test_device_samplers(ctxs):
     """Philox samplers in HBM: distributional checks (OpenFHE's PRNG stream is not reproducible), determinism per
     (seed, stream), independence across streams, exact range of the uniform limbs."""

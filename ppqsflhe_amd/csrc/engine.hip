@@ -14,6 +14,7 @@
 // workgroup (blockIdx.y), so all per-limb constants sit in SGPRs.
 #include "engine.hpp"
 #include "ntt_radix.hpp"
+#include "fused_kernels.hpp"
 #include "codec_kernels.hpp"
 #include "sampler_kernels.hpp"
 
@@ -440,6 +441,8 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
         int v = std::atoi(e);
         if (v >= 1 && v <= 64) chunk_ = (uint32_t)v;
     }
+    if (const char *e = std::getenv("MKCKKS_FUSE_ICOL")) fuse_icol_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MKCKKS_ICOL_VARIANT")) icol_variant_ = std::atoi(e);
     if (device_ < 0) return;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= device_)
@@ -635,7 +638,7 @@ const u64 *Engine::limb_vector(const std::string &key, const std::vector<u64> &v
     return d;
 }
 
-static DevConv to_dev(const BaseConvTable &t, const u64 *d_hat) {
+static DevConv to_dev(const BaseConvTable &t, const u64 *d_hat, const u64 *d_hat_fp) {
     if (t.src.size() > (size_t)MAX_CONV_IN || t.dst.size() > (size_t)MAX_CONV_OUT)
         throw std::invalid_argument("base conversion larger than supported");
     DevConv c{};
@@ -648,7 +651,22 @@ static DevConv to_dev(const BaseConvTable &t, const u64 *d_hat) {
     }
     for (size_t j = 0; j < t.dst.size(); ++j) c.dst_id[j] = t.dst[j];
     c.hat = d_hat;
+    c.hat_d = reinterpret_cast<const double *>(d_hat_fp);
+    c.hatq_d = c.hat_d + t.hat.size();
     return c;
+}
+
+// [S/s_i]_t and [S/s_i]_t / t as doubles (bit patterns), [n_in][n_out] each: the fp64 form of the conversion matrix
+static std::vector<u64> hat_as_doubles(const BaseConvTable &t, const std::vector<u64> &moduli) {
+    const size_t cnt = t.hat.size(), n_out = t.dst.size();
+    std::vector<u64> v(2 * cnt);
+    for (size_t e = 0; e < cnt; ++e) {
+        const long double q = (long double)moduli[t.dst[e % n_out]];
+        const double h = (double)t.hat[e], hq = (double)((long double)t.hat[e] / q);
+        std::memcpy(&v[e], &h, 8);
+        std::memcpy(&v[cnt + e], &hq, 8);
+    }
+    return v;
 }
 
 const DevConv &Engine::modup_conv(uint32_t nl, uint32_t part) {
@@ -656,8 +674,9 @@ const DevConv &Engine::modup_conv(uint32_t nl, uint32_t part) {
     auto it = modup_cache_.find(key);
     if (it != modup_cache_.end()) return it->second;
     BaseConvTable t = ps_.modup_table(nl, part);
-    const u64 *d_hat = limb_vector("modup_hat_" + std::to_string(nl) + "_" + std::to_string(part), t.hat);
-    DevConv c = to_dev(t, d_hat);
+    const std::string tag = std::to_string(nl) + "_" + std::to_string(part);
+    const u64 *d_hat = limb_vector("modup_hat_" + tag, t.hat);
+    DevConv c = to_dev(t, d_hat, limb_vector("modup_hatd_" + tag, hat_as_doubles(t, ps_.moduli)));
     const uint32_t lo = part * ps_.alpha;
     for (uint32_t i = 0; i < c.n_in; ++i) c.src_slot[i] = lo + i;  // slot inside the nl-limb input polynomial
     // targets: all slots of the extended polynomial except the digit's own
@@ -672,10 +691,101 @@ const DevConv &Engine::moddown_conv(uint32_t nl) {
     if (it != moddown_cache_.end()) return it->second;
     BaseConvTable t = ps_.moddown_table(nl);
     const u64 *d_hat = limb_vector("moddown_hat_" + std::to_string(nl), t.hat);
-    DevConv c = to_dev(t, d_hat);
+    DevConv c = to_dev(t, d_hat, limb_vector("moddown_hatd_" + std::to_string(nl), hat_as_doubles(t, ps_.moduli)));
     for (uint32_t k = 0; k < c.n_in; ++k) c.src_slot[k] = k;
     for (uint32_t i = 0; i < c.n_out; ++i) c.dst_slot[i] = i;
     return moddown_cache_.emplace(nl, c).first->second;
+}
+
+// device array of the conversion tables of level nl: digits 0 .. nparts-1, then ModDown's (index nparts)
+const DevConv *Engine::conv_set(uint32_t nl) {
+    auto it = conv_set_cache_.find(nl);
+    if (it != conv_set_cache_.end()) return it->second;
+    const uint32_t nparts = ps_.num_parts(nl);
+    std::vector<DevConv> h;
+    for (uint32_t part = 0; part < nparts; ++part) h.push_back(modup_conv(nl, part));
+    h.push_back(moddown_conv(nl));
+    DevConv *d = nullptr;
+    MK_HIP(hipMalloc(&d, h.size() * sizeof(DevConv)));
+    MK_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(DevConv), hipMemcpyHostToDevice));
+    owned_.push_back(d);
+    conv_set_cache_[nl] = d;
+    return d;
+}
+
+// source-class pattern of a conversion for k_icol_conv_col: 0 = all integer, 1 = all fp64, 2 = source 0 integer and
+// the rest fp64; -1 = none of these (the caller falls back to the separate inverse column pass + k_conv_col)
+int Engine::conv_src_mode(const DevConv &cv) const {
+    bool all_fp = true, all_int = true, rest_fp = true;
+    for (uint32_t i = 0; i < cv.n_in; ++i) {
+        const bool fp = fp_of_[cv.src_id[i]] != 0;
+        all_fp = all_fp && fp;
+        all_int = all_int && !fp;
+        if (i > 0) rest_fp = rest_fp && fp;
+    }
+    if (all_int) return 0;
+    if (all_fp) return 1;
+    return (!fp_of_[cv.src_id[0]] && rest_fp) ? 2 : -1;
+}
+
+// k_icol_conv_col keeps N_IN * H source words per thread in registers: H = 16 takes up to 4 sources, H = 8 up to 4 too
+// (instances are compiled for 1..4 sources; larger digits keep the two-kernel path)
+static bool icol_shape_ok(int log_h, uint32_t n_in) { return (log_h == 3 || log_h == 4) && n_in >= 1 && n_in <= 4; }
+
+template <int LOG_H, int N_IN>
+static void launch_icol_mode(const FusedIo &io, const NttTables &T, const DevConv *cvs, int mode, hipStream_t s) {
+    const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
+    const dim3 grid(io.items * io.nparts * tiles);
+    switch (mode) {
+        case 0: k_icol_conv_col<LOG_H, N_IN, 0><<<grid, NTT_THREADS, 0, s>>>(io, T, cvs); break;
+        case 1: k_icol_conv_col<LOG_H, N_IN, 1><<<grid, NTT_THREADS, 0, s>>>(io, T, cvs); break;
+        case 2: k_icol_conv_col<LOG_H, N_IN, (N_IN > 1 ? 2 : 0)><<<grid, NTT_THREADS, 0, s>>>(io, T, cvs); break;
+        default: throw std::logic_error("unsupported source classes for the fused conversion");
+    }
+}
+template <int LOG_H>
+static void launch_icol_h(const FusedIo &io, const NttTables &T, const DevConv *cvs, uint32_t n_in, int mode, hipStream_t s) {
+    switch (n_in) {
+        case 1: launch_icol_mode<LOG_H, 1>(io, T, cvs, mode, s); break;
+        case 2: launch_icol_mode<LOG_H, 2>(io, T, cvs, mode, s); break;
+        case 3: launch_icol_mode<LOG_H, 3>(io, T, cvs, mode, s); break;
+        case 4: launch_icol_mode<LOG_H, 4>(io, T, cvs, mode, s); break;
+        default: throw std::logic_error("fused conversion fan-in unsupported");
+    }
+}
+template <int N_IN, int S, int MINW>
+static void launch_icol3_mode(const FusedIo &io, const NttTables &T, const DevConv *cvs, int mode, hipStream_t s) {
+    const uint32_t tiles = (1u << T.log_r2) / S;
+    const dim3 grid(io.items * io.nparts * tiles);
+    switch (mode) {
+        case 0: k_icol3_conv_col<N_IN, 0, S, MINW><<<grid, 32 * S, 0, s>>>(io, T, cvs); break;
+        case 1: k_icol3_conv_col<N_IN, 1, S, MINW><<<grid, 32 * S, 0, s>>>(io, T, cvs); break;
+        case 2: k_icol3_conv_col<N_IN, (N_IN > 1 ? 2 : 0), S, MINW><<<grid, 32 * S, 0, s>>>(io, T, cvs); break;
+        default: throw std::logic_error("unsupported source classes for the fused conversion");
+    }
+}
+static void launch_icol(const FusedIo &io, const NttTables &T, const DevConv *cvs, uint32_t n_in, int mode, int variant,
+                        hipStream_t s) {
+    if (!io.items || !io.nparts) return;
+    if (T.log_r1 == 8) {  // 256-point columns: three rounds, 8 words per thread
+        switch (n_in) {
+            case 1: launch_icol3_mode<1, 16, 4>(io, T, cvs, mode, s); break;
+            case 2: launch_icol3_mode<2, 16, 4>(io, T, cvs, mode, s); break;
+            case 3: launch_icol3_mode<3, 16, 4>(io, T, cvs, mode, s); break;
+            case 4:
+                if (variant == 2) launch_icol3_mode<4, 16, 2>(io, T, cvs, mode, s);
+                else if (variant == 3) launch_icol3_mode<4, 8, 3>(io, T, cvs, mode, s);
+                else if (variant == 4) launch_icol3_mode<4, 8, 2>(io, T, cvs, mode, s);
+                else launch_icol3_mode<4, 16, 4>(io, T, cvs, mode, s);
+                break;
+            default: throw std::logic_error("fused conversion fan-in unsupported");
+        }
+    } else if (T.log_r1 == 6) {  // 64-point columns: two rounds of radix 8
+        launch_icol_h<3>(io, T, cvs, n_in, mode, s);
+    } else {
+        throw std::logic_error("fused conversion needs 64- or 256-point columns");
+    }
+    MK_HIP(hipGetLastError());
 }
 
 template <int N_IN>
@@ -1052,9 +1162,28 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
     bool fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0;
     // S1: c1 -> COEFFICIENT format, scaled by N^-1 * Qhat_inv
     NttIo s1{c1, coef, c1_stride, (size_t)nl * n, 0, 0, 0, nl, nl};
-    ntt_passes(s1, tabs_, cnt, true, fold, fold + D, lanes(), fused ? 1 : 0);
     const size_t dstride = (size_t)nparts * ext * n;
-    for (uint32_t part = 0; part < nparts && fused; ++part) {
+    const bool icol = fused && icol_ok(nl);
+    if (icol) {
+        // inverse ROW pass only; its column pass runs inside k_icol_conv_col together with the conversion and the
+        // forward column pass of every target (the coefficient-format digits stay in registers)
+        launch_row<true>(s1, tabs_, cnt, TailArgs{}, lanes());
+        const DevConv *cvs = conv_set(nl);
+        for (uint32_t part = 0; part < nparts;) {  // one launch per run of digits with equal fan-in and source classes
+            const DevConv &cv = modup_conv(nl, part);
+            const int mode = conv_src_mode(cv);
+            uint32_t run = 1;
+            while (part + run < nparts && modup_conv(nl, part + run).n_in == cv.n_in &&
+                   conv_src_mode(modup_conv(nl, part + run)) == mode)
+                ++run;
+            FusedIo io{coef, dig, (size_t)nl * n, dstride, (size_t)ext * n, cnt, part, run, fold, fold + D};
+            launch_icol(io, tabs_, cvs, cv.n_in, mode, icol_variant_, stream_);
+            part += run;
+        }
+    } else {
+        ntt_passes(s1, tabs_, cnt, true, fold, fold + D, lanes(), fused ? 1 : 0);
+    }
+    for (uint32_t part = 0; part < nparts && fused && !icol; ++part) {
         // S2+S3a: base conversion fused into the column pass of each complement limb
         ConvIo io{coef, dig + (size_t)part * ext * n, (size_t)nl * n, dstride, cnt, 0, 0};
         launch_conv_col(io, tabs_, modup_conv(nl, part), lanes());
@@ -1086,19 +1215,45 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
     }
 }
 
-// INTT of the P limbs (til -> pc); with rows_done the inverse row pass already happened inside the fused inner-product
-// kernel and only the (scaling, packing) inverse column pass remains, in place on pc
-void Engine::inverse_p_limbs(const NttIo &s5, uint32_t cnt, const u64 *scale, const u64 *scale_sh, int pack, bool rows_done) {
-    if (!rows_done) {
-        ntt_passes(s5, tabs_, cnt, true, scale, scale_sh, lanes(), pack);
+// every digit of level nl (and ModDown's P -> Q_l conversion) fits k_icol_conv_col
+bool Engine::icol_ok(uint32_t nl) {
+    if (!fuse_icol_) return false;
+    const int lh = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2);
+    for (uint32_t part = 0; part < ps_.num_parts(nl); ++part) {
+        const DevConv &cv = modup_conv(nl, part);
+        if (!icol_shape_ok(lh, cv.n_in) || conv_src_mode(cv) < 0) return false;
+    }
+    const DevConv &md = moddown_conv(nl);
+    return icol_shape_ok(lh, md.n_in) && conv_src_mode(md) >= 0;
+}
+
+// first half of ApproxModDown on `cnt` polynomials: INTT of the P limbs of til (scaled by N^-1 * Phat^-1), conversion
+// P -> Q_l, forward column pass of the converted limbs -> conv [cnt][nl][N] (the row pass + tail follow).  pc is the
+// scratch of the P limbs between the passes; with rows_done the inverse ROW pass already happened inside the fused
+// inner-product kernel and pc holds its output.
+void Engine::moddown_convert(const u64 *til, u64 *pc, u64 *conv, uint32_t cnt, uint32_t nl, bool rows_done) {
+    const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, D = ps_.D;
+    const u64 *fold = folded_scale(nl);
+    NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
+    const DevConv &cv = moddown_conv(nl);
+    if (icol_ok(nl)) {
+        if (!rows_done) launch_row<true>(s5, tabs_, cnt, TailArgs{}, lanes());
+        FusedIo io{pc, conv, (size_t)K * n, (size_t)nl * n, 0, cnt, ps_.num_parts(nl), 1, fold, fold + D};
+        launch_icol(io, tabs_, conv_set(nl), cv.n_in, conv_src_mode(cv), icol_variant_, stream_);
         return;
     }
-    NttIo second = s5;
-    second.in = s5.out;
-    second.in_stride = s5.out_stride;
-    second.in_slot0 = s5.out_slot0;
-    launch_col<true>(second, tabs_, cnt, scale, scale_sh, lanes(), pack);
-    MK_HIP(hipGetLastError());
+    if (!rows_done) {
+        ntt_passes(s5, tabs_, cnt, true, fold, fold + D, lanes(), 1);
+    } else {
+        NttIo second = s5;
+        second.in = s5.out;
+        second.in_stride = s5.out_stride;
+        second.in_slot0 = s5.out_slot0;
+        launch_col<true>(second, tabs_, cnt, fold, fold + D, lanes(), 1);
+        MK_HIP(hipGetLastError());
+    }
+    ConvIo io{pc, conv, (size_t)K * n, (size_t)nl * n, cnt, 0, 0};
+    launch_conv_col(io, tabs_, cv, lanes());
 }
 
 // ApproxModDown on `cnt` polynomials til[item][ext][N] -> out[item] (items out_stride apart, nl limbs each);
@@ -1109,13 +1264,10 @@ void Engine::moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t o
     const u64 *fold = folded_scale(nl), *pinv = p_inverse(nl);
     const bool conv_fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0;  // conversion inside the column pass
     const bool tail_fused = conv_fused && row_tail_supported(tabs_);               // tail inside the row pass
-    NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
-    inverse_p_limbs(s5, cnt, fold, fold + D, conv_fused ? 1 : 0, p_rows_done);
     const DevConv &cv = moddown_conv(nl);
-    ConvIo io{pc, conv, (size_t)K * n, (size_t)nl * n, cnt, 0, 0};
     EwGeom g{n, nl, ps_.L};
     if (tail_fused) {
-        launch_conv_col(io, tabs_, cv, lanes());
+        moddown_convert(til, pc, conv, cnt, nl, p_rows_done);
         // row pass of the converted limbs with the (ctilde_Q - conv) * P^-1 (+ c0) tail in its copy-out
         NttIo row{conv, out, (size_t)nl * n, out_stride, 0, 0, 0, nl, nl};
         TailArgs tail{til, add, pinv, pinv + nl, add_stride, ext, 1, accumulate ? 1u : 0u};
@@ -1123,11 +1275,14 @@ void Engine::moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t o
         MK_HIP(hipGetLastError());
         return;
     }
-    if (conv_fused) {  // e.g. N = 2^17: fused conversion + column pass, plain row pass, tail as its own kernel
-        launch_conv_col(io, tabs_, cv, lanes());
+    if (conv_fused) {  // fused conversion + column pass, plain row pass, tail as its own kernel
+        moddown_convert(til, pc, conv, cnt, nl, p_rows_done);
         NttIo row{conv, conv, (size_t)nl * n, (size_t)nl * n, 0, 0, 0, nl, nl};
         launch_row<false>(row, tabs_, cnt, TailArgs{}, lanes());
     } else {
+        if (p_rows_done) throw std::logic_error("fused P-limb inverse needs the radix kernels");
+        NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
+        ntt_passes(s5, tabs_, cnt, true, fold, fold + D, lanes(), 0);
         launch_baseconv(pc, (size_t)K * n, conv, (size_t)nl * n, cv, d_limb_, n, cnt, 1, stream_);
         ntt_launch(conv, cnt, nl, nl, false, nullptr, nullptr);
     }
@@ -1437,10 +1592,7 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
                 const u64 *c1 = ct + (size_t)nl * n;
                 const bool p_rows = keyswitch_digits(c1, ct_words, evk, coef, dig, til, pc, cnt, nl);
                 // ModDown up to the column pass of the converted limbs
-                NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
-                inverse_p_limbs(s5, 2 * cnt, fold, fold + D, 1, p_rows);
-                ConvIo io{pc, conv, (size_t)K * n, (size_t)nl * n, 2 * cnt, 0, 0};
-                launch_conv_col(io, tabs_, moddown_conv(nl), lanes());
+                moddown_convert(til, pc, conv, 2 * cnt, nl, p_rows);
             }
             stream_ = main;
             cur_lane_ = 0;

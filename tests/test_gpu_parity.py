@@ -379,31 +379,39 @@ def test_reencrypt_sum(ctxs, name, nl, C, B):
 
 @pytest.mark.parametrize("env", [{"MKCKKS_FUSE_INNER": "0"}, {"MKCKKS_SUM_PAIR": "0"},
                                  {"MKCKKS_FUSE_INNER": "0", "MKCKKS_SUM_PAIR": "0"},
-                                 {"MKCKKS_ROW3X": "1"}, {"MKCKKS_ROW3X": "0"},  # three-round vs two-round 256-point kernels
+                                 {"MKCKKS_ROW3X": "1"},  # three-round instead of two-round 256-point kernels
                                  {"MKCKKS_FUSE_INNER_INT": "0"},  # integer limbs: separate row pass + inner product
-                                 {"MKCKKS_FUSE_P_INVERSE": "0"}])  # P limbs: accumulators to HBM, separate inverse row pass
+                                 {"MKCKKS_FUSE_P_INVERSE": "0"},  # P limbs: accumulators to HBM, separate inverse row pass
+                                 {"MKCKKS_FUSE_ICOL": "0"},       # separate inverse column pass + k_conv_col
+                                 {"MKCKKS_SUM_ONE_LANE": "1"}])   # clients strictly one after the other
 def test_unfused_kernel_paths_stay_bit_exact(ctxs, monkeypatch, env):
-    """The separate row pass + inner product and the one-client-per-iteration sum kernel remain in the library (other
-    ring sizes, switches for A/B measurements): same bits as the fused default and as the oracle at N = 2^16."""
+    """Every non-default kernel path the library keeps behind a switch (other ring sizes fall back to them, A/B
+    measurements use them): a context created under the switch must give the same bits as the default context and as
+    the oracle at N = 2^16.  Switches are read once, when a context is created."""
+    from ppqsflhe_amd import Context
     g, o = ctxs("c3")
     nl, C, B = 12, 3, 1
     rng = np.random.default_rng(77)
     cts = np.stack([rand_ct(rng, g, nl, B) for _ in range(C)])
     evks = np.stack([rand_polys(rng, g, list(range(g.D)) * (2 * g.beta), 1).reshape(g.beta, 2, g.D, g.N)
                      for _ in range(C)])
-    d_cts, d_evks = g.to_device(cts), g.to_device(evks)
     d_ref = g.empty((B, 2, nl, g.N))
-    g.reencrypt_sum(d_cts, d_evks, d_ref, C, B, nl)
+    g.reencrypt_sum(g.to_device(cts), g.to_device(evks), d_ref, C, B, nl)
     want = d_ref.to_host()
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    d_out = g.empty((B, 2, nl, g.N))
-    g.reencrypt_sum(d_cts, d_evks, d_out, C, B, nl)
-    got = d_out.to_host()
-    assert np.array_equal(got, want)
-    d_one = g.empty((B, 2, nl, g.N))
-    g.reencrypt(g.to_device(cts[0]), g.to_device(evks[0]), d_one, B, nl)
-    assert np.array_equal(d_one.to_host()[0], o.reencrypt(cts[0, 0], evks[0]))
+    a = CONFIGS["c3"]
+    g2 = Context(a[0], a[1], a[2], a[3], dnum=a[4], device=0)
+    try:
+        d_cts, d_evks = g2.to_device(cts), g2.to_device(evks)
+        d_out = g2.empty((B, 2, nl, g.N))
+        g2.reencrypt_sum(d_cts, d_evks, d_out, C, B, nl)
+        assert np.array_equal(d_out.to_host(), want)
+        d_one = g2.empty((B, 2, nl, g.N))
+        g2.reencrypt(g2.to_device(cts[0]), g2.to_device(evks[0]), d_one, B, nl)
+        assert np.array_equal(d_one.to_host()[0], o.reencrypt(cts[0, 0], evks[0]))
+    finally:
+        g2.close()
 
 
 def test_fused_path_across_workspace_chunks(ctxs, monkeypatch):

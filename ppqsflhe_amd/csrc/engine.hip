@@ -14,7 +14,6 @@
 // workgroup (blockIdx.y), so all per-limb constants sit in SGPRs.
 #include "engine.hpp"
 #include "ntt_radix.hpp"
-#include "fused_kernels.hpp"
 #include "codec_kernels.hpp"
 #include "sampler_kernels.hpp"
 
@@ -441,8 +440,7 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
         int v = std::atoi(e);
         if (v >= 1 && v <= 64) chunk_ = (uint32_t)v;
     }
-    if (const char *e = std::getenv("MKCKKS_FUSE_ICOL")) fuse_icol_ = std::atoi(e) != 0;
-    if (const char *e = std::getenv("MKCKKS_ICOL_VARIANT")) icol_variant_ = std::atoi(e);
+    if (const char *e = std::getenv("MKCKKS_CONV_FP")) conv_fp_ = std::atoi(e) != 0;
     if (device_ < 0) return;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= device_)
@@ -697,24 +695,8 @@ const DevConv &Engine::moddown_conv(uint32_t nl) {
     return moddown_cache_.emplace(nl, c).first->second;
 }
 
-// device array of the conversion tables of level nl: digits 0 .. nparts-1, then ModDown's (index nparts)
-const DevConv *Engine::conv_set(uint32_t nl) {
-    auto it = conv_set_cache_.find(nl);
-    if (it != conv_set_cache_.end()) return it->second;
-    const uint32_t nparts = ps_.num_parts(nl);
-    std::vector<DevConv> h;
-    for (uint32_t part = 0; part < nparts; ++part) h.push_back(modup_conv(nl, part));
-    h.push_back(moddown_conv(nl));
-    DevConv *d = nullptr;
-    MK_HIP(hipMalloc(&d, h.size() * sizeof(DevConv)));
-    MK_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(DevConv), hipMemcpyHostToDevice));
-    owned_.push_back(d);
-    conv_set_cache_[nl] = d;
-    return d;
-}
-
-// source-class pattern of a conversion for k_icol_conv_col: 0 = all integer, 1 = all fp64, 2 = source 0 integer and
-// the rest fp64; -1 = none of these (the caller falls back to the separate inverse column pass + k_conv_col)
+// source-class pattern of a conversion for k_conv_col: 0 = all integer, 1 = all fp64, 2 = source 0 integer and
+// the rest fp64; -1 = none of these (the caller then interchanges every source as packed 30-bit halves)
 int Engine::conv_src_mode(const DevConv &cv) const {
     bool all_fp = true, all_int = true, rest_fp = true;
     for (uint32_t i = 0; i < cv.n_in; ++i) {
@@ -726,66 +708,6 @@ int Engine::conv_src_mode(const DevConv &cv) const {
     if (all_int) return 0;
     if (all_fp) return 1;
     return (!fp_of_[cv.src_id[0]] && rest_fp) ? 2 : -1;
-}
-
-// k_icol_conv_col keeps N_IN * H source words per thread in registers: H = 16 takes up to 4 sources, H = 8 up to 4 too
-// (instances are compiled for 1..4 sources; larger digits keep the two-kernel path)
-static bool icol_shape_ok(int log_h, uint32_t n_in) { return (log_h == 3 || log_h == 4) && n_in >= 1 && n_in <= 4; }
-
-template <int LOG_H, int N_IN>
-static void launch_icol_mode(const FusedIo &io, const NttTables &T, const DevConv *cvs, int mode, hipStream_t s) {
-    const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
-    const dim3 grid(io.items * io.nparts * tiles);
-    switch (mode) {
-        case 0: k_icol_conv_col<LOG_H, N_IN, 0><<<grid, NTT_THREADS, 0, s>>>(io, T, cvs); break;
-        case 1: k_icol_conv_col<LOG_H, N_IN, 1><<<grid, NTT_THREADS, 0, s>>>(io, T, cvs); break;
-        case 2: k_icol_conv_col<LOG_H, N_IN, (N_IN > 1 ? 2 : 0)><<<grid, NTT_THREADS, 0, s>>>(io, T, cvs); break;
-        default: throw std::logic_error("unsupported source classes for the fused conversion");
-    }
-}
-template <int LOG_H>
-static void launch_icol_h(const FusedIo &io, const NttTables &T, const DevConv *cvs, uint32_t n_in, int mode, hipStream_t s) {
-    switch (n_in) {
-        case 1: launch_icol_mode<LOG_H, 1>(io, T, cvs, mode, s); break;
-        case 2: launch_icol_mode<LOG_H, 2>(io, T, cvs, mode, s); break;
-        case 3: launch_icol_mode<LOG_H, 3>(io, T, cvs, mode, s); break;
-        case 4: launch_icol_mode<LOG_H, 4>(io, T, cvs, mode, s); break;
-        default: throw std::logic_error("fused conversion fan-in unsupported");
-    }
-}
-template <int N_IN, int S, int MINW>
-static void launch_icol3_mode(const FusedIo &io, const NttTables &T, const DevConv *cvs, int mode, hipStream_t s) {
-    const uint32_t tiles = (1u << T.log_r2) / S;
-    const dim3 grid(io.items * io.nparts * tiles);
-    switch (mode) {
-        case 0: k_icol3_conv_col<N_IN, 0, S, MINW><<<grid, 32 * S, 0, s>>>(io, T, cvs); break;
-        case 1: k_icol3_conv_col<N_IN, 1, S, MINW><<<grid, 32 * S, 0, s>>>(io, T, cvs); break;
-        case 2: k_icol3_conv_col<N_IN, (N_IN > 1 ? 2 : 0), S, MINW><<<grid, 32 * S, 0, s>>>(io, T, cvs); break;
-        default: throw std::logic_error("unsupported source classes for the fused conversion");
-    }
-}
-static void launch_icol(const FusedIo &io, const NttTables &T, const DevConv *cvs, uint32_t n_in, int mode, int variant,
-                        hipStream_t s) {
-    if (!io.items || !io.nparts) return;
-    if (T.log_r1 == 8) {  // 256-point columns: three rounds, 8 words per thread
-        switch (n_in) {
-            case 1: launch_icol3_mode<1, 16, 4>(io, T, cvs, mode, s); break;
-            case 2: launch_icol3_mode<2, 16, 4>(io, T, cvs, mode, s); break;
-            case 3: launch_icol3_mode<3, 16, 4>(io, T, cvs, mode, s); break;
-            case 4:
-                if (variant == 2) launch_icol3_mode<4, 16, 2>(io, T, cvs, mode, s);
-                else if (variant == 3) launch_icol3_mode<4, 8, 3>(io, T, cvs, mode, s);
-                else if (variant == 4) launch_icol3_mode<4, 8, 2>(io, T, cvs, mode, s);
-                else launch_icol3_mode<4, 16, 4>(io, T, cvs, mode, s);
-                break;
-            default: throw std::logic_error("fused conversion fan-in unsupported");
-        }
-    } else if (T.log_r1 == 6) {  // 64-point columns: two rounds of radix 8
-        launch_icol_h<3>(io, T, cvs, n_in, mode, s);
-    } else {
-        throw std::logic_error("fused conversion needs 64- or 256-point columns");
-    }
-    MK_HIP(hipGetLastError());
 }
 
 template <int N_IN>
@@ -950,8 +872,26 @@ static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inve
 
 // base conversion fused into the forward column pass of every converted limb (k_conv_col); false when the
 // column pass of this ring size has no radix kernel (the caller then runs k_baseconv + a plain column pass)
+template <int LOG_H, int N_IN, int SRCMODE>
+static void launch_conv_col_n(const ConvIo &io, const ConvIo &iof, const dim3 &grid, const dim3 &gridf, const NttTables &T,
+                              const DevConv &cv, const Lanes &ln) {
+    launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
+        [&](hipStream_t s) { k_conv_col<LOG_H, N_IN, false, DevConv, SRCMODE><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
+        [&](hipStream_t s) { k_conv_col<LOG_H, N_IN, true, DevConv, SRCMODE><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
+}
+template <int LOG_H, int N_IN>
+static void launch_conv_col_m(const ConvIo &io, const ConvIo &iof, const dim3 &grid, const dim3 &gridf, const NttTables &T,
+                              const DevConv &cv, const Lanes &ln, int srcmode) {
+    if constexpr (N_IN <= 4 && LOG_H >= 3) {
+        if (srcmode == 1) return launch_conv_col_n<LOG_H, N_IN, 1>(io, iof, grid, gridf, T, cv, ln);
+        if (srcmode == 2) return launch_conv_col_n<LOG_H, N_IN, (N_IN > 1 ? 2 : 0)>(io, iof, grid, gridf, T, cv, ln);
+    }
+    if (srcmode != 0) throw std::logic_error("double conversion sources: unsupported shape");
+    launch_conv_col_n<LOG_H, N_IN, 0>(io, iof, grid, gridf, T, cv, ln);
+}
+// srcmode: form of the sources in io.in (see src_is_double): 0 = packed 30-bit halves, 1 / 2 = doubles
 template <int LOG_H>
-static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, const Lanes &ln) {
+static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, const Lanes &ln, int srcmode) {
     const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
     ConvIo io = io0, iof = io0;
     io.target_mask = iof.target_mask = 0;
@@ -961,54 +901,22 @@ static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevCo
     iof.nsel = (uint32_t)__builtin_popcountll(iof.target_mask);
     const dim3 grid(io.items * tiles * io.nsel), gridf(io.items * tiles * iof.nsel);
     switch (cv.n_in) {
-        case 1:
-            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
-                [&](hipStream_t s) { k_conv_col<LOG_H, 1, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
-                [&](hipStream_t s) { k_conv_col<LOG_H, 1, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
-            break;
-        case 2:
-            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
-                [&](hipStream_t s) { k_conv_col<LOG_H, 2, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
-                [&](hipStream_t s) { k_conv_col<LOG_H, 2, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
-            break;
-        case 3:
-            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
-                [&](hipStream_t s) { k_conv_col<LOG_H, 3, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
-                [&](hipStream_t s) { k_conv_col<LOG_H, 3, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
-            break;
-        case 4:
-            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
-                [&](hipStream_t s) { k_conv_col<LOG_H, 4, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
-                [&](hipStream_t s) { k_conv_col<LOG_H, 4, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
-            break;
-        case 5:
-            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
-                [&](hipStream_t s) { k_conv_col<LOG_H, 5, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
-                [&](hipStream_t s) { k_conv_col<LOG_H, 5, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
-            break;
-        case 6:
-            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
-                [&](hipStream_t s) { k_conv_col<LOG_H, 6, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
-                [&](hipStream_t s) { k_conv_col<LOG_H, 6, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
-            break;
-        case 7:
-            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
-                [&](hipStream_t s) { k_conv_col<LOG_H, 7, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
-                [&](hipStream_t s) { k_conv_col<LOG_H, 7, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
-            break;
-        case 8:
-            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
-                [&](hipStream_t s) { k_conv_col<LOG_H, 8, false, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
-                [&](hipStream_t s) { k_conv_col<LOG_H, 8, true, DevConv><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
-            break;
+        case 1: launch_conv_col_m<LOG_H, 1>(io, iof, grid, gridf, T, cv, ln, srcmode); break;
+        case 2: launch_conv_col_m<LOG_H, 2>(io, iof, grid, gridf, T, cv, ln, srcmode); break;
+        case 3: launch_conv_col_m<LOG_H, 3>(io, iof, grid, gridf, T, cv, ln, srcmode); break;
+        case 4: launch_conv_col_m<LOG_H, 4>(io, iof, grid, gridf, T, cv, ln, srcmode); break;
+        case 5: launch_conv_col_m<LOG_H, 5>(io, iof, grid, gridf, T, cv, ln, srcmode); break;
+        case 6: launch_conv_col_m<LOG_H, 6>(io, iof, grid, gridf, T, cv, ln, srcmode); break;
+        case 7: launch_conv_col_m<LOG_H, 7>(io, iof, grid, gridf, T, cv, ln, srcmode); break;
+        case 8: launch_conv_col_m<LOG_H, 8>(io, iof, grid, gridf, T, cv, ln, srcmode); break;
         default: throw std::invalid_argument("base conversion fan-in unsupported");
     }
 }
-static bool launch_conv_col(const ConvIo &io, const NttTables &T, const DevConv &cv, const Lanes &s) {
+static bool launch_conv_col(const ConvIo &io, const NttTables &T, const DevConv &cv, const Lanes &s, int srcmode = 0) {
     switch (fast_log_h(T.log_r1, 1u << T.log_r2)) {
-        case 4: launch_conv_col_h<4>(io, T, cv, s); break;
-        case 3: launch_conv_col_h<3>(io, T, cv, s); break;
-        case 2: launch_conv_col_h<2>(io, T, cv, s); break;
+        case 4: launch_conv_col_h<4>(io, T, cv, s, srcmode); break;
+        case 3: launch_conv_col_h<3>(io, T, cv, s, srcmode); break;
+        case 2: launch_conv_col_h<2>(io, T, cv, s, srcmode); break;
         default: return false;
     }
     MK_HIP(hipGetLastError());
@@ -1163,30 +1071,19 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
     // S1: c1 -> COEFFICIENT format, scaled by N^-1 * Qhat_inv
     NttIo s1{c1, coef, c1_stride, (size_t)nl * n, 0, 0, 0, nl, nl};
     const size_t dstride = (size_t)nparts * ext * n;
-    const bool icol = fused && icol_ok(nl);
-    if (icol) {
-        // inverse ROW pass only; its column pass runs inside k_icol_conv_col together with the conversion and the
-        // forward column pass of every target (the coefficient-format digits stay in registers)
-        launch_row<true>(s1, tabs_, cnt, TailArgs{}, lanes());
-        const DevConv *cvs = conv_set(nl);
-        for (uint32_t part = 0; part < nparts;) {  // one launch per run of digits with equal fan-in and source classes
-            const DevConv &cv = modup_conv(nl, part);
-            const int mode = conv_src_mode(cv);
-            uint32_t run = 1;
-            while (part + run < nparts && modup_conv(nl, part + run).n_in == cv.n_in &&
-                   conv_src_mode(modup_conv(nl, part + run)) == mode)
-                ++run;
-            FusedIo io{coef, dig, (size_t)nl * n, dstride, (size_t)ext * n, cnt, part, run, fold, fold + D};
-            launch_icol(io, tabs_, cvs, cv.n_in, mode, icol_variant_, stream_);
-            part += run;
-        }
-    } else {
-        ntt_passes(s1, tabs_, cnt, true, fold, fold + D, lanes(), fused ? 1 : 0);
+    // interchange format of the coefficient-form digits: fp64-class limbs as canonical doubles when every digit is
+    // "all fp64-class" or "q_0 first, then fp64-class" (k_conv_col's SRCMODE 1 / 2), else packed halves throughout
+    bool doubles = fused && conv_fp_ && tabs_.has_fp && fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) >= 3;
+    for (uint32_t part = 0; part < nparts && doubles; ++part) {
+        const DevConv &cv = modup_conv(nl, part);
+        if (conv_src_mode(cv) < 0 || (conv_src_mode(cv) != 0 && cv.n_in > 4)) doubles = false;
     }
-    for (uint32_t part = 0; part < nparts && fused && !icol; ++part) {
+    ntt_passes(s1, tabs_, cnt, true, fold, fold + D, lanes(), fused ? (doubles ? 2 : 1) : 0);
+    for (uint32_t part = 0; part < nparts && fused; ++part) {
         // S2+S3a: base conversion fused into the column pass of each complement limb
         ConvIo io{coef, dig + (size_t)part * ext * n, (size_t)nl * n, dstride, cnt, 0, 0};
-        launch_conv_col(io, tabs_, modup_conv(nl, part), lanes());
+        const DevConv &cv = modup_conv(nl, part);
+        launch_conv_col(io, tabs_, cv, lanes(), doubles ? conv_src_mode(cv) : 0);
     }
     if (fused) {
         // S3b: one row pass over every converted limb of every digit (own limbs skipped)
@@ -1215,18 +1112,6 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
     }
 }
 
-// every digit of level nl (and ModDown's P -> Q_l conversion) fits k_icol_conv_col
-bool Engine::icol_ok(uint32_t nl) {
-    if (!fuse_icol_) return false;
-    const int lh = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2);
-    for (uint32_t part = 0; part < ps_.num_parts(nl); ++part) {
-        const DevConv &cv = modup_conv(nl, part);
-        if (!icol_shape_ok(lh, cv.n_in) || conv_src_mode(cv) < 0) return false;
-    }
-    const DevConv &md = moddown_conv(nl);
-    return icol_shape_ok(lh, md.n_in) && conv_src_mode(md) >= 0;
-}
-
 // first half of ApproxModDown on `cnt` polynomials: INTT of the P limbs of til (scaled by N^-1 * Phat^-1), conversion
 // P -> Q_l, forward column pass of the converted limbs -> conv [cnt][nl][N] (the row pass + tail follow).  pc is the
 // scratch of the P limbs between the passes; with rows_done the inverse ROW pass already happened inside the fused
@@ -1236,12 +1121,6 @@ void Engine::moddown_convert(const u64 *til, u64 *pc, u64 *conv, uint32_t cnt, u
     const u64 *fold = folded_scale(nl);
     NttIo s5{til, pc, (size_t)ext * n, (size_t)K * n, nl, 0, nl, K, nl};
     const DevConv &cv = moddown_conv(nl);
-    if (icol_ok(nl)) {
-        if (!rows_done) launch_row<true>(s5, tabs_, cnt, TailArgs{}, lanes());
-        FusedIo io{pc, conv, (size_t)K * n, (size_t)nl * n, 0, cnt, ps_.num_parts(nl), 1, fold, fold + D};
-        launch_icol(io, tabs_, conv_set(nl), cv.n_in, conv_src_mode(cv), icol_variant_, stream_);
-        return;
-    }
     if (!rows_done) {
         ntt_passes(s5, tabs_, cnt, true, fold, fold + D, lanes(), 1);
     } else {
@@ -1545,7 +1424,7 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
             reencrypt(cts + (size_t)c * n_ct * ct_words, evks + (size_t)c * evk_words, out, n_ct, nl, c != 0);
         return;
     }
-    const u64 *fold = folded_scale(nl), *pinv = p_inverse(nl);
+    const u64 *pinv = p_inverse(nl);
     const int log_h = fast_row(tabs_.log_r2, 1u << tabs_.log_r1);  // 9: three-round kernels on 512-point rows
     for (uint32_t b0 = 0; b0 < n_ct; b0 += chunk_) {
         const uint32_t cnt = n_ct - b0 < chunk_ ? n_ct - b0 : chunk_;

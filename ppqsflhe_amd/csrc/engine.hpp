@@ -32,7 +32,7 @@ struct NoDevice : std::runtime_error {
 constexpr int MAX_CONV_IN = 8;    // alpha, K <= 8
 constexpr int MAX_CONV_OUT = 40;  // complement limbs of one digit
 
-// device image of one BaseConvTable: passed to k_conv_col by value, read from a device array by k_icol_conv_col
+// device image of one BaseConvTable, passed to k_conv_col by value (constant/SGPR space)
 struct DevConv {
     uint32_t n_in, n_out;
     uint32_t src_id[MAX_CONV_IN];     // limb ids of the sources
@@ -125,9 +125,7 @@ private:
     void moddown_core(const u64 *til, u64 *pc, u64 *conv, u64 *out, size_t out_stride, const u64 *add,
                       size_t add_stride, uint32_t cnt, uint32_t nl, bool accumulate, bool p_rows_done = false);
     void moddown_convert(const u64 *til, u64 *pc, u64 *conv, uint32_t cnt, uint32_t nl, bool rows_done);
-    const DevConv *conv_set(uint32_t nl);
     int conv_src_mode(const DevConv &cv) const;
-    bool icol_ok(uint32_t nl);
 
     ParamSet ps_;
     int device_ = -1;
@@ -156,9 +154,7 @@ private:
     uint32_t chunk_ = 16;  // ciphertexts per key-switch launch group (MKCKKS_CHUNK overrides)
     std::map<std::pair<uint32_t, uint32_t>, DevConv> modup_cache_;
     std::map<uint32_t, DevConv> moddown_cache_;
-    std::map<uint32_t, DevConv *> conv_set_cache_;
-    bool fuse_icol_ = true;  // MKCKKS_FUSE_ICOL=0: separate inverse column pass + k_conv_col
-    int icol_variant_ = 1;   // geometry / occupancy variant of k_icol3_conv_col (A/B measurements)
+    bool conv_fp_ = true;  // MKCKKS_CONV_FP=0: conversion sources always as packed 30-bit halves
     std::map<std::string, u64 *> vec_cache_;
     std::vector<void *> owned_;
 };

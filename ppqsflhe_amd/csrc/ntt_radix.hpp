@@ -355,9 +355,17 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
         const u64 sc_sh = scale ? scale_sh[id] : (FP ? dbits(lc.ninv_qd) : lc.ninv_sh);
 #pragma unroll
         for (int k = 0; k < H; ++k) {
-            const u64 v = FP ? fp_to_canonical(fp_mulmod(bitsd(x[k]), bitsd(sc), bitsd(sc_sh), lc.qd), lc.qd, lc.qinv)
-                                : shoup_mul(x[k], sc, sc_sh, lc.q);
-            st_pass(dst + (size_t)(j + H * k) * r2, pack ? pack30(v) : v);  // packed halves feed k_conv_col directly
+            if (FP && pack == 2) {
+                // canonical residue as a double for k_conv_col's fp64 products: |x| <= 1.33 q -> |s| <= 0.92 q, so one
+                // conditional add lands in [0, q) (the same value fp_to_canonical returns)
+                double sd = fp_mulmod(bitsd(x[k]), bitsd(sc), bitsd(sc_sh), lc.qd);
+                sd = sd < 0.0 ? sd + lc.qd : sd;
+                st_pass(dst + (size_t)(j + H * k) * r2, dbits(sd));
+            } else {
+                const u64 v = FP ? fp_to_canonical(fp_mulmod(bitsd(x[k]), bitsd(sc), bitsd(sc_sh), lc.qd), lc.qd, lc.qinv)
+                                 : shoup_mul(x[k], sc, sc_sh, lc.q);
+                st_pass(dst + (size_t)(j + H * k) * r2, pack ? pack30(v) : v);  // packed halves feed k_conv_col directly
+            }
         }
     }
 }
@@ -376,10 +384,23 @@ struct ConvIo {
     unsigned long long target_mask;  // targets (indices into cv.dst_*) of this instance's arithmetic class
     uint32_t nsel;                   // popcount(target_mask)
 };
-template <int LOG_H, int N_IN, bool FP, typename CONV>
+// canonical integer below 2^52 held in a double -> its 30-bit halves (what split30 gives for the u64)
+MK_D void split30_d(u64 dbl_bits, uint32_t &lo, uint32_t &hi) {
+    const u64 b = dbits(bitsd(dbl_bits) + 4503599627370496.0) & 0xFFFFFFFFFFFFFull;  // mantissa of 2^52 + v is v
+    lo = (uint32_t)b & 0x3FFFFFFFu;
+    hi = (uint32_t)(b >> 30);
+}
+// form in which source i reaches k_conv_col under SRCMODE: 0 = every source as packed 30-bit halves, 1 = every source
+// a canonical double (all sources of the digit are fp64-class limbs), 2 = source 0 packed (60-bit q_0), the rest doubles
+template <int SRCMODE>
+MK_D constexpr bool src_is_double(int i) {
+    return SRCMODE == 1 || (SRCMODE == 2 && i > 0);
+}
+template <int LOG_H, int N_IN, bool FP, typename CONV, int SRCMODE = 0>
 __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T, CONV cv) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
+    static_assert(SRCMODE == 0 || N_IN <= 4, "double sources: at most 4 per digit");
     __shared__ u64 lds[TL::WORDS];
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
     const uint32_t groups = io.items * tiles;  // source tiles
@@ -402,19 +423,56 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
     u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jt] * n + tile * S + c;
     u64 x[H];
     if (N_IN <= 4) {
-        // sources and [S/s_i]_t are below 2^60: 30-bit column accumulation, pure v_mad_u64_u32 chains
+        // packed sources and [S/s_i]_t are below 2^60: 30-bit column accumulation, pure v_mad_u64_u32 chains.
+        // Sources that arrive as doubles (fp64-class limbs, below 1.25 * 2^50): an fp64-class target takes their
+        // products x_i * [S/s_i]_t mod t on the FMA unit (6 operations instead of 4 mads + a share of the Barrett
+        // step); an integer-class target splits them back into 30-bit halves.
         uint32_t h0[N_IN], h1[N_IN];
+        double hd[N_IN], hq[N_IN];
 #pragma unroll
-        for (int i = 0; i < N_IN; ++i) split30(cv.hat[i * cv.n_out + jt], h0[i], h1[i]);
+        for (int i = 0; i < N_IN; ++i) {
+            if (FP && src_is_double<SRCMODE>(i)) {
+                hd[i] = cv.hat_d[i * cv.n_out + jt];
+                hq[i] = cv.hatq_d[i * cv.n_out + jt];
+            } else {
+                split30(cv.hat[i * cv.n_out + jt], h0[i], h1[i]);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < H; ++k) {
-            Cols acc{0, 0, 0};
+            u64 p[N_IN];
 #pragma unroll
-            for (int i = 0; i < N_IN; ++i) {
-                const u64 p = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2];
-                mac_cols(acc, (uint32_t)p, (uint32_t)(p >> 32), h0[i], h1[i]);
+            for (int i = 0; i < N_IN; ++i) p[i] = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2];
+            if (FP && SRCMODE != 0) {
+                double acc = 0.0;
+                if (SRCMODE == 2) {  // the packed source(s): column accumulation, below 4q < 2^53
+                    Cols ia{0, 0, 0};
+#pragma unroll
+                    for (int i = 0; i < N_IN; ++i)
+                        if (!src_is_double<SRCMODE>(i)) mac_cols(ia, (uint32_t)p[i], (uint32_t)(p[i] >> 32), h0[i], h1[i]);
+                    acc = (double)reduce_cols_lazy(ia, lc);
+                }
+#pragma unroll
+                for (int i = 0; i < N_IN; ++i)
+                    if (src_is_double<SRCMODE>(i)) acc += fp_mulmod(bitsd(p[i]), hd[i], hq[i], lc.qd);
+                // |acc| <= 4q + 4 * 0.8q < 2^53: exact; into the rounds' range
+                x[k] = dbits(fp_reduce(acc, lc.qd, lc.qinv));
+            } else {
+                Cols acc{0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < N_IN; ++i) {
+                    uint32_t a0, a1;
+                    if (src_is_double<SRCMODE>(i)) {
+                        split30_d(p[i], a0, a1);
+                    } else {
+                        a0 = (uint32_t)p[i];
+                        a1 = (uint32_t)(p[i] >> 32);
+                    }
+                    mac_cols(acc, a0, a1, h0[i], h1[i]);
+                }
+                x[k] = reduce_cols_lazy(acc, lc);  // < 4q: the first butterfly stage accepts < 8q
+                if (FP) x[k] = dbits(fp_reduce((double)x[k], lc.qd, lc.qinv));  // < 4q < 2^53: exact in a double
             }
-            x[k] = reduce_cols_lazy(acc, lc);  // < 4q: the first butterfly stage accepts < 8q
         }
     } else {
         // 5..8 sources (e.g. alpha = K = 7 at L = 20): same 30-bit columns with the middle one split in two
@@ -430,11 +488,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
                 mac_cols4(acc, (uint32_t)p, (uint32_t)(p >> 32), h0[i], h1[i]);
             }
             x[k] = reduce_cols4(acc, lc);
+            if (FP) x[k] = dbits(fp_reduce((double)x[k], lc.qd, lc.qinv));
         }
-    }
-    if (FP) {  // < 4q < 2^53: exact in a double; bring into the fp rounds' range
-#pragma unroll
-        for (int k = 0; k < H; ++k) x[k] = dbits(fp_reduce((double)x[k], lc.qd, lc.qinv));
     }
     col_forward_finish<LOG_H, FP>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
 }

@@ -382,7 +382,7 @@ def test_reencrypt_sum(ctxs, name, nl, C, B):
                                  {"MKCKKS_ROW3X": "1"},  # three-round instead of two-round 256-point kernels
                                  {"MKCKKS_FUSE_INNER_INT": "0"},  # integer limbs: separate row pass + inner product
                                  {"MKCKKS_FUSE_P_INVERSE": "0"},  # P limbs: accumulators to HBM, separate inverse row pass
-                                 {"MKCKKS_FUSE_ICOL": "0"},       # separate inverse column pass + k_conv_col
+                                 {"MKCKKS_CONV_FP": "0"},         # conversion sources as packed 30-bit halves for every target
                                  {"MKCKKS_SUM_ONE_LANE": "1"}])   # clients strictly one after the other
 def test_unfused_kernel_paths_stay_bit_exact(ctxs, monkeypatch, env):
     """Every non-default kernel path the library keeps behind a switch (other ring sizes fall back to them, A/B

@@ -14,6 +14,7 @@
 // workgroup (blockIdx.y), so all per-limb constants sit in SGPRs.
 #include "engine.hpp"
 #include "ntt_radix.hpp"
+#include "qsum_kernels.hpp"
 #include "codec_kernels.hpp"
 #include "sampler_kernels.hpp"
 
@@ -435,12 +436,35 @@ static dim3 ew_grid(uint32_t n, uint32_t slots, uint32_t items) {
     return dim3((n / 2 + EW_THREADS - 1) / EW_THREADS, slots, items);
 }
 
-Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
+// Switches are read ONCE, when a context is created (tests and A/B runs create a context under the switch).
+static bool env_flag(const char *name, bool dflt) {
+    const char *e = std::getenv(name);
+    return e ? std::atoi(e) != 0 : dflt;
+}
+Knobs Knobs::from_env() {
+    Knobs k;
     if (const char *e = std::getenv("MKCKKS_CHUNK")) {
-        int v = std::atoi(e);
-        if (v >= 1 && v <= 64) chunk_ = (uint32_t)v;
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 64) k.chunk = (uint32_t)v;
     }
-    if (const char *e = std::getenv("MKCKKS_CONV_FP")) conv_fp_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MKCKKS_QSUM_GROUP")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 64) k.qsum_group = (uint32_t)v;
+    }
+    k.generic_ntt = env_flag("MKCKKS_GENERIC_NTT", k.generic_ntt);
+    k.no_fp64 = env_flag("MKCKKS_NO_FP64", k.no_fp64);
+    k.fuse_inner = env_flag("MKCKKS_FUSE_INNER", k.fuse_inner);
+    k.fuse_inner_int = env_flag("MKCKKS_FUSE_INNER_INT", k.fuse_inner_int);
+    k.fuse_p_inverse = env_flag("MKCKKS_FUSE_P_INVERSE", k.fuse_p_inverse);
+    k.sum_pair = env_flag("MKCKKS_SUM_PAIR", k.sum_pair);
+    k.row3x = env_flag("MKCKKS_ROW3X", k.row3x);
+    k.one_lane = env_flag("MKCKKS_SUM_ONE_LANE", k.one_lane);
+    k.conv_fp = env_flag("MKCKKS_CONV_FP", k.conv_fp);
+    k.qsum = env_flag("MKCKKS_QSUM", k.qsum);
+    return k;
+}
+
+Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device), knobs_(Knobs::from_env()) {
     if (device_ < 0) return;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= device_)
@@ -451,13 +475,11 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
     tabs_.log_n = ps_.log_n;
     tabs_.log_r1 = (ps_.log_n % 2 == 0) ? ((ps_.log_n / 2) & ~1u) : ps_.log_n / 2;
     tabs_.log_r2 = ps_.log_n - tabs_.log_r1;
-    if (const char *e = std::getenv("MKCKKS_GENERIC_NTT"))
-        if (std::atoi(e) == 1) { tabs_.log_r1 = ps_.log_n / 2; tabs_.log_r2 = ps_.log_n - tabs_.log_r1; }
+    if (knobs_.generic_ntt) { tabs_.log_r1 = ps_.log_n / 2; tabs_.log_r2 = ps_.log_n - tabs_.log_r1; }
     // fp64 limbs: only when BOTH passes run on the radix kernels (the generic LDS-stage kernels are integer-only)
     // and the modulus is below 1.25 * 2^50 (bounds in ntt_radix.hpp).  MKCKKS_NO_FP64=1 keeps everything integer.
     const bool radix_both = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) && fast_row(tabs_.log_r2, 1u << tabs_.log_r1);
-    const char *nofp = std::getenv("MKCKKS_NO_FP64");
-    const bool fp_ok = radix_both && !(nofp && std::atoi(nofp) == 1);
+    const bool fp_ok = radix_both && !knobs_.no_fp64;
     tabs_.has_fp = 0;
     fp_of_.assign(D, 0);
     for (uint32_t i = 0; i < D; ++i) {
@@ -466,23 +488,9 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device) {
         tabs_.has_fp |= ps_.limb[i].fp;
     }
     tabs_.h_fp_of = fp_of_.data();
-    {
-        // measured on MI355X: forking the two instances onto two streams costs more (event round trips) than the
-        // overlapped tail waves return (-5 %), so it stays off unless asked for
-        const char *e = std::getenv("MKCKKS_TWO_LANES");
-        two_lanes_ = e && std::atoi(e) == 1;
-        MK_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
-        MK_HIP(hipStreamCreateWithFlags(&sum_stream_, hipStreamNonBlocking));
-        MK_HIP(hipEventCreateWithFlags(&ev_a_, hipEventDisableTiming));
-        MK_HIP(hipEventCreateWithFlags(&ev_b_, hipEventDisableTiming));
-        MK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-        MK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-        for (auto &st : extra_lane_) MK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        for (auto &ev : ev_lane_) MK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        for (auto &st : aux_stream_) MK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        for (auto &ev : ev_conv_) MK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        for (auto &ev : ev_aux_) MK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
+    MK_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));  // second client lane of reencrypt_sum
+    MK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    MK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     MK_HIP(hipMalloc(&d_limb_, D * sizeof(LimbConst)));
     MK_HIP(hipMemcpy(d_limb_, ps_.limb.data(), D * sizeof(LimbConst), hipMemcpyHostToDevice));
     const size_t tbytes = (size_t)D * n * sizeof(u64);
@@ -553,31 +561,11 @@ Engine::~Engine() {
         if (p) (void)hipFree(p);
     for (void *p : owned_) (void)hipFree(p);
     if (side_stream_) (void)hipStreamDestroy(side_stream_);
-    if (sum_stream_) (void)hipStreamDestroy(sum_stream_);
-    if (ev_a_) (void)hipEventDestroy(ev_a_);
-    if (ev_b_) (void)hipEventDestroy(ev_b_);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
-    for (auto st : extra_lane_)
-        if (st) (void)hipStreamDestroy(st);
-    for (auto ev : ev_lane_)
-        if (ev) (void)hipEventDestroy(ev);
-    for (auto st : aux_stream_)
-        if (st) (void)hipStreamDestroy(st);
-    for (auto ev : ev_conv_)
-        if (ev) (void)hipEventDestroy(ev);
-    for (auto ev : ev_aux_)
-        if (ev) (void)hipEventDestroy(ev);
 }
 
-Lanes Engine::lanes() const {
-    Lanes ln;
-    ln.main = stream_;
-    ln.side = two_lanes_ ? side_stream_ : nullptr;
-    ln.fork = ev_fork_;
-    ln.join = ev_join_;
-    return ln;
-}
+Lanes Engine::lanes() const { return Lanes{stream_}; }
 
 void Engine::need_device() const {
     if (device_ < 0) throw NoDevice("host-only context: no device operations");
@@ -747,22 +735,12 @@ static int fast_row(uint32_t log_r2, uint32_t rows) {
     return fast_log_h(log_r2, rows);
 }
 
-// pack != 0 (inverse radix kernels only): results leave as packed 30-bit halves for k_conv_col
-// The integer and the fp64 instance of a pass touch disjoint limbs: when both have work they are launched on two
-// streams (fork/join with events) so the partial last waves of one overlap the other.
+// The integer and the fp64 instance of a pass touch disjoint limbs and are launched one after the other on the same
+// stream (forking them onto two streams was measured slower: -5 %, event round trips).
 template <typename FInt, typename FFp>
 static void launch_two_classes(const Lanes &ln, bool has_int, bool has_fp, FInt &&launch_int, FFp &&launch_fp) {
-    if (has_int && has_fp && ln.side) {
-        MK_HIP(hipEventRecord(ln.fork, ln.main));
-        MK_HIP(hipStreamWaitEvent(ln.side, ln.fork, 0));
-        launch_int(ln.main);
-        launch_fp(ln.side);
-        MK_HIP(hipEventRecord(ln.join, ln.side));
-        MK_HIP(hipStreamWaitEvent(ln.main, ln.join, 0));
-    } else {
-        if (has_int) launch_int(ln.main);
-        if (has_fp) launch_fp(ln.main);
-    }
+    if (has_int) launch_int(ln.main);
+    if (has_fp) launch_fp(ln.main);
 }
 
 // slots of `io` whose limb runs on the fp64 (want_fp) or the integer instance; fp_of: per-limb-id class (host copy)
@@ -856,6 +834,7 @@ static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inve
                        const u64 *scale_sh, const Lanes &s, int pack = 0) {
     if (n_polys == 0 || io.nslots == 0) return;
     NttIo second = io;  // second pass runs in place on the output
+    second.in_group = 0;
     second.in = io.out;
     second.in_stride = io.out_stride;
     second.in_slot0 = io.out_slot0;
@@ -1063,17 +1042,19 @@ const u64 *Engine::p_inverse(uint32_t nl) {
 // EvalKeySwitchPrecomputeCore on `cnt` polynomials c1 (items ct_stride apart): fills the converted limbs of
 // dig[item][part][ext][N] in EVALUATION format; the digits' own limbs are NOT copied (readers take them from c1).
 void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, uint32_t cnt, uint32_t nl,
-                        bool rows_int_only, hipEvent_t conv_done) {
+                        bool rows_int_only, uint32_t in_group, size_t in_gstride) {
     const uint32_t n = ps_.n, ext = nl + ps_.K, nparts = ps_.num_parts(nl), D = ps_.D;
     const u64 *fold = folded_scale(nl);
     // the fused conversion kernel exists when the column pass has a radix kernel; it reads packed 30-bit halves
     bool fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0;
     // S1: c1 -> COEFFICIENT format, scaled by N^-1 * Qhat_inv
     NttIo s1{c1, coef, c1_stride, (size_t)nl * n, 0, 0, 0, nl, nl};
+    s1.in_group = in_group;  // n-client flow: polynomial p is c1 of cts[p / in_group][p % in_group]
+    s1.in_gstride = in_gstride;
     const size_t dstride = (size_t)nparts * ext * n;
     // interchange format of the coefficient-form digits: fp64-class limbs as canonical doubles when every digit is
     // "all fp64-class" or "q_0 first, then fp64-class" (k_conv_col's SRCMODE 1 / 2), else packed halves throughout
-    bool doubles = fused && conv_fp_ && tabs_.has_fp && fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) >= 3;
+    bool doubles = fused && knobs_.conv_fp && tabs_.has_fp && fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) >= 3;
     for (uint32_t part = 0; part < nparts && doubles; ++part) {
         const DevConv &cv = modup_conv(nl, part);
         if (conv_src_mode(cv) < 0 || (conv_src_mode(cv) != 0 && cv.n_in > 4)) doubles = false;
@@ -1088,9 +1069,7 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
     if (fused) {
         // S3b: one row pass over every converted limb of every digit (own limbs skipped)
         NttIo row{dig, dig, (size_t)ext * n, (size_t)ext * n, 0, 0, 0, ext, nl, nparts, ps_.alpha};
-        // (rows_int_only: the fp64 limbs finish their transform inside the fused inner-product kernel, which may
-        // start as soon as the conversions are done: conv_done)
-        if (conv_done) MK_HIP(hipEventRecord(conv_done, stream_));
+        // (rows_int_only: the fp64 limbs finish their transform inside the fused inner-product kernel)
         if (!skip_rows_) launch_row<false>(row, tabs_, cnt * nparts, TailArgs{}, lanes(), rows_int_only ? 1u : 3u);
         MK_HIP(hipGetLastError());
         return;
@@ -1211,10 +1190,8 @@ template <int LOG_H, int NPARTS>
 static void launch_row_inner_fp(const InnerArgs &a, const NttTables &T, hipStream_t s) {
     const uint32_t tiles = (1u << T.log_r1) / (256u >> LOG_H);
     // 2 waves per SIMD: 196 VGPRs, no spills; measured 18.35 k ct/s against 17.9 k at 3 waves (168 VGPRs, 28 spilled)
-    static const int waves = [] { const char *e = std::getenv("MKCKKS_INNER_WAVES"); return e ? std::atoi(e) : 2; }();
     const dim3 grid(tiles * a.nsel * a.items);
-    if (waves == 3) k_row_inner_fp<LOG_H, NPARTS, 3><<<grid, NTT_THREADS, 0, s>>>(a, T);
-    else k_row_inner_fp<LOG_H, NPARTS, 2><<<grid, NTT_THREADS, 0, s>>>(a, T);
+    k_row_inner_fp<LOG_H, NPARTS, 2><<<grid, NTT_THREADS, 0, s>>>(a, T);
 }
 template <int LOG_H>
 static void launch_row_inner_fp_n(const InnerArgs &a, const NttTables &T, uint32_t nparts, hipStream_t s) {
@@ -1230,11 +1207,7 @@ static void launch_row_inner_fp_n(const InnerArgs &a, const NttTables &T, uint32
 }
 
 // 256-point rows have two implementations of the fused kernels: two rounds of radix 16 (16 words per thread, 2 waves
-// per SIMD) and three rounds 8 x 8 x 4 (8 words per thread, 3 waves per SIMD); MKCKKS_ROW3X picks
-static bool three_round_256() {
-    const char *e = std::getenv("MKCKKS_ROW3X");
-    return e && std::atoi(e) != 0;
-}
+// per SIMD) and three rounds 8 x 8 x 4 (8 words per thread, 3 waves per SIMD); Knobs::row3x picks
 
 template <int LOGC>
 static void launch_row3_inner_fp_n(const InnerArgs &a, const NttTables &T, uint32_t nparts, hipStream_t s) {
@@ -1287,54 +1260,39 @@ static void launch_row3_inner_int_n(const InnerArgs &a, const NttTables &T, uint
 // S1-S4 of the hybrid key switch for `cnt` ciphertexts: ModUp digits of c1 (EvalKeySwitchPrecomputeCore) and their
 // inner product with the eval key over Q_l P (EvalFastKeySwitchCoreExt) -> til [cnt][2][ext][N].
 // With the radix kernels the fp64 Q limbs finish their forward transform inside k_row_inner_fp (digits stay on chip);
-// integer limbs (q0, P) take the row pass + k_inner_product_b, which keeps the eval key in registers across the batch.
+// integer limbs (q0, P) take k_row3_inner_int, or the row pass + k_inner_product_b on ring sizes without it.
 bool Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u64 *coef, u64 *dig, u64 *til, u64 *pc,
                               uint32_t cnt, uint32_t nl) {
     const uint32_t n = ps_.n, ext = nl + ps_.K, nparts = ps_.num_parts(nl), D = ps_.D;
-    const char *fe = std::getenv("MKCKKS_FUSE_INNER");  // read per call: the tests run both paths in one process
-    const bool fuse_env = !fe || std::atoi(fe) != 0;
     const int row_h = fast_row(tabs_.log_r2, 1u << tabs_.log_r1);
     unsigned long long fp_mask = 0, all_mask = ext >= 64 ? ~0ull : ((1ull << ext) - 1);
     for (uint32_t i = 0; i < nl; ++i)
         if (tabs_.h_fp_of[i]) fp_mask |= 1ull << i;
-    const bool fuse = fuse_env && fp_mask != 0 && (row_h == 3 || row_h == 4 || row_h == 9) &&
+    const bool fuse = knobs_.fuse_inner && fp_mask != 0 && (row_h == 3 || row_h == 4 || row_h == 9) &&
                       fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0;
-    const char *fk = std::getenv("MKCKKS_INNER_FORK");
-    const bool fork = fuse && aux_stream_[0] != nullptr && fk && std::atoi(fk) != 0;  // measured: -2.7 %, off
-    const uint32_t lane = cur_lane_ < MAX_SUM_LANES ? cur_lane_ : 0;
-    const char *fi = std::getenv("MKCKKS_FUSE_INNER_INT");
-    const bool fuse_int = fuse && (row_h == 4 || row_h == 9) && (!fi || std::atoi(fi) != 0);  // +1.3 % at C3
+    const bool fuse_int = fuse && (row_h == 4 || row_h == 9) && knobs_.fuse_inner_int;  // +1.3 % at C3
     {
         struct Reset {  // cleared on every exit path: the public ModUp entry point must never inherit it
             bool &flag;
             ~Reset() { flag = false; }
         } reset{skip_rows_};
         skip_rows_ = fuse_int;  // no separate row pass at all: both classes finish inside the fused kernels
-        modup_core(c1, ct_stride, coef, dig, cnt, nl, fuse, fork ? ev_conv_[lane] : nullptr);
+        modup_core(c1, ct_stride, coef, dig, cnt, nl, fuse);
     }
     if (fuse) {
-        // the fused fp64 kernel and the integer row pass + inner product touch disjoint limbs: side by side
-        hipStream_t fs = stream_;
-        if (fork) {
-            fs = aux_stream_[lane];
-            MK_HIP(hipStreamWaitEvent(fs, ev_conv_[lane], 0));
-        }
         InnerArgs a{dig, c1, evk, til, ct_stride, nl, ext, D, ps_.alpha, cnt, fp_mask,
                     (uint32_t)__builtin_popcountll(fp_mask)};
-        if (row_h == 9) launch_row3_inner_fp_n<3>(a, tabs_, nparts, fs);
-        else if (row_h == 4 && three_round_256()) launch_row3_inner_fp_n<2>(a, tabs_, nparts, fs);
-        else if (row_h == 4) launch_row_inner_fp_n<4>(a, tabs_, nparts, fs);
-        else launch_row_inner_fp_n<3>(a, tabs_, nparts, fs);
-        if (fork) MK_HIP(hipEventRecord(ev_aux_[lane], fs));
+        if (row_h == 9) launch_row3_inner_fp_n<3>(a, tabs_, nparts, stream_);
+        else if (row_h == 4 && knobs_.row3x) launch_row3_inner_fp_n<2>(a, tabs_, nparts, stream_);
+        else if (row_h == 4) launch_row_inner_fp_n<4>(a, tabs_, nparts, stream_);
+        else launch_row_inner_fp_n<3>(a, tabs_, nparts, stream_);
     }
     const unsigned long long mask = fuse ? (all_mask & ~fp_mask) : all_mask;
     if (fuse_int) {  // integer limbs: row pass + inner product in one three-round kernel as well
         InnerArgs a{dig, c1, evk, til, ct_stride, nl, ext, D, ps_.alpha, cnt, mask, (uint32_t)__builtin_popcountll(mask)};
-        const char *pi = std::getenv("MKCKKS_FUSE_P_INVERSE");
-        u64 *pc_fused = (pc && (!pi || std::atoi(pi) != 0)) ? pc : nullptr;
+        u64 *pc_fused = (pc && knobs_.fuse_p_inverse) ? pc : nullptr;
         if (row_h == 9) launch_row3_inner_int_n<3>(a, tabs_, nparts, ps_.L, pc_fused, ps_.K, stream_);
         else launch_row3_inner_int_n<2>(a, tabs_, nparts, ps_.L, pc_fused, ps_.K, stream_);
-        if (fork) MK_HIP(hipStreamWaitEvent(stream_, ev_aux_[lane], 0));
         MK_HIP(hipGetLastError());
         return pc_fused != nullptr;
     }
@@ -1348,7 +1306,6 @@ bool Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u
         case 6: launch_inner<6>(dig, c1, ct_stride, evk, til, g, d_limb_, ext, D, ps_.alpha, cnt, mask, stream_); break;
         default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
     }
-    if (fork) MK_HIP(hipStreamWaitEvent(stream_, ev_aux_[lane], 0));
     MK_HIP(hipGetLastError());
     return false;
 }
@@ -1368,77 +1325,168 @@ void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t c
     moddown_core(til, pc, conv, out, (size_t)nl * n, ct, ct_stride, 2 * cnt, nl, accumulate, p_rows);
 }
 
+// classes: bit 0 = integer-class limbs, bit 1 = fp64-class limbs
 template <int LOGC>
-static void launch_row3_tail_sum(SumArgs a, const NttTables &T, hipStream_t s, hipStream_t s_int) {
+static void launch_row3_tail_sum(SumArgs a, const NttTables &T, hipStream_t s, unsigned classes = 3) {
     const uint32_t tiles = (1u << T.log_r1) / RowT<LOGC>::ROWS;
     SumArgs ai = a, af = a;
     ai.slot_mask = af.slot_mask = 0;
     for (uint32_t i = 0; i < a.nl; ++i) (T.h_fp_of[i] ? af.slot_mask : ai.slot_mask) |= 1ull << i;
     ai.nsel = (uint32_t)__builtin_popcountll(ai.slot_mask);
     af.nsel = (uint32_t)__builtin_popcountll(af.slot_mask);
-    if (ai.nsel) k_row3_tail_sum<false, LOGC><<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s_int>>>(ai, T);
-    if (af.nsel) k_row3_tail_sum<true, LOGC><<<dim3(tiles * af.nsel * a.n_polys), NTT_THREADS, 0, s>>>(af, T);
+    if (ai.nsel && (classes & 1)) k_row3_tail_sum<false, LOGC><<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s>>>(ai, T);
+    if (af.nsel && (classes & 2)) k_row3_tail_sum<true, LOGC><<<dim3(tiles * af.nsel * a.n_polys), NTT_THREADS, 0, s>>>(af, T);
 }
 
-
 template <int LOG_H>
-static void launch_row_tail_sum(SumArgs a, const NttTables &T, uint32_t L, hipStream_t s, hipStream_t s_int) {
+static void launch_row_tail_sum(SumArgs a, const NttTables &T, bool pair, hipStream_t s, unsigned classes = 3) {
     const uint32_t tiles = (1u << T.log_r1) / (256u >> LOG_H);
     SumArgs ai = a, af = a;
     ai.slot_mask = af.slot_mask = 0;
     for (uint32_t i = 0; i < a.nl; ++i) (T.h_fp_of[i] ? af.slot_mask : ai.slot_mask) |= 1ull << i;
     ai.nsel = (uint32_t)__builtin_popcountll(ai.slot_mask);
     af.nsel = (uint32_t)__builtin_popcountll(af.slot_mask);
-    (void)L;
-    static const int waves = [] { const char *e = std::getenv("MKCKKS_SUM_WAVES"); return e ? std::atoi(e) : 2; }();  // 2: no spills (212 VGPRs); measured equal to 3, faster than 4
+    if (!(classes & 1)) ai.nsel = 0;
+    if (!(classes & 2)) af.nsel = 0;
     const dim3 gi(tiles * ai.nsel * a.n_polys), gf(tiles * af.nsel * a.n_polys);
-    // two clients per workgroup iteration (shared twiddle fetches, two dependency chains): the default
-    const char *pe = std::getenv("MKCKKS_SUM_PAIR");  // read per call: the tests run both kernels in one process
-    const bool pair = !pe || std::atoi(pe) != 0;
+    // two clients per workgroup iteration (shared twiddle fetches, two dependency chains): the default; 2 waves per
+    // SIMD either way (212 VGPRs, no spills; measured equal to 3 waves, faster than 4)
     if (pair && LOG_H == 4) {
-        if (ai.nsel) k_row_tail_sum2<LOG_H, false><<<gi, NTT_THREADS, 0, s_int>>>(ai, T);
+        if (ai.nsel) k_row_tail_sum2<LOG_H, false><<<gi, NTT_THREADS, 0, s>>>(ai, T);
         if (af.nsel) k_row_tail_sum2<LOG_H, true><<<gf, NTT_THREADS, 0, s>>>(af, T);
-    } else if (waves == 2) {
-        if (ai.nsel) k_row_tail_sum<LOG_H, false, 2><<<gi, NTT_THREADS, 0, s_int>>>(ai, T);
-        if (af.nsel) k_row_tail_sum<LOG_H, true, 2><<<gf, NTT_THREADS, 0, s>>>(af, T);
-    } else if (waves == 4) {
-        if (ai.nsel) k_row_tail_sum<LOG_H, false, 4><<<gi, NTT_THREADS, 0, s_int>>>(ai, T);
-        if (af.nsel) k_row_tail_sum<LOG_H, true, 4><<<gf, NTT_THREADS, 0, s>>>(af, T);
     } else {
-        if (ai.nsel) k_row_tail_sum<LOG_H, false, 3><<<gi, NTT_THREADS, 0, s_int>>>(ai, T);
-        if (af.nsel) k_row_tail_sum<LOG_H, true, 3><<<gf, NTT_THREADS, 0, s>>>(af, T);
+        if (a.til_compact) throw std::logic_error("compact accumulators need the paired sum kernel");
+        if (ai.nsel) k_row_tail_sum<LOG_H, false, 2><<<gi, NTT_THREADS, 0, s>>>(ai, T);
+        if (af.nsel) k_row_tail_sum<LOG_H, true, 2><<<gf, NTT_THREADS, 0, s>>>(af, T);
     }
 }
 
-// sum over clients of ReEncrypt(ct_c[b], evk_c): everything up to the column pass of ModDown runs per client (two
-// clients in flight on two streams), the last row pass + tail + sum is one kernel over all clients.
-void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n_clients, uint32_t n_ct, uint32_t nl) {
-    need_device();
-    check_nl(nl);
-    if (!n_clients || !n_ct) return;
+template <int LOG_H>
+static void launch_qsum_fp(const QSumArgs &a, const NttTables &T, uint32_t nparts, hipStream_t s) {
+    const uint32_t tiles = (1u << T.log_r1) / (256u >> LOG_H);
+    const dim3 grid(tiles * a.nsel * a.cnt);
+    switch (nparts) {
+        case 1: k_qsum_fp<LOG_H, 1><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 2: k_qsum_fp<LOG_H, 2><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 3: k_qsum_fp<LOG_H, 3><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 4: k_qsum_fp<LOG_H, 4><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 5: k_qsum_fp<LOG_H, 5><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 6: k_qsum_fp<LOG_H, 6><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
+    }
+}
+
+// per Q limb: P mod q, (P mod q)/q, P^-1 mod q, (P^-1 mod q)/q as doubles (fp64-class limbs; zeros elsewhere)
+const u64 *Engine::p_doubles() {
+    auto it = vec_cache_.find("p_doubles");
+    if (it != vec_cache_.end()) return it->second;
+    std::vector<u64> v(4 * (size_t)ps_.L, 0);
+    for (uint32_t i = 0; i < ps_.L; ++i) {
+        if (!ps_.limb[i].fp) continue;
+        const long double q = (long double)ps_.moduli[i];
+        const u64 pm = ps_.p_mod(i), pi = ps_.p_inv_mod(i);
+        const double d[4] = {(double)pm, (double)((long double)pm / q), (double)pi, (double)((long double)pi / q)};
+        std::memcpy(&v[4 * (size_t)i], d, sizeof(d));
+    }
+    return limb_vector("p_doubles", v);
+}
+
+// the merged n-client flow needs: radix column kernels, 256-point two-round row kernels (k_qsum_fp, k_row3_inner_int,
+// k_row_tail_sum2 exist for them), fp64-class Q limbs, and the fused integer inner product
+bool Engine::qsum_ok(uint32_t nl) const {
+    if (!knobs_.qsum || !knobs_.fuse_inner || !knobs_.fuse_inner_int || !knobs_.fuse_p_inverse || !knobs_.sum_pair ||
+        knobs_.row3x)
+        return false;
+    if (fast_row(tabs_.log_r2, 1u << tabs_.log_r1) != 4 || fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) == 0) return false;
+    for (uint32_t i = 0; i < nl; ++i)
+        if (tabs_.h_fp_of[i]) return true;
+    return false;
+}
+
+// sum over clients of ReEncrypt(ct_c[b], evk_c).  Merged flow (N = 2^14, 2^16 with fp64-class limbs): per chunk of
+// ciphertext indices and group of clients, every phase is ONE launch over all (client, index) items:
+//   ModUp of c1 -> converted digits (column-passed)                          modup_core
+//   P limbs: row pass + eval-key inner product + inverse row pass            k_row3_inner_int<.., true>
+//   ApproxModDown's conversion P -> Q_l (column-passed)                      moddown_convert
+//   integer-class Q limbs (q_0): inner product, then row pass + tail + sum   k_row3_inner_int<.., false>, k_row_tail_sum2
+//   fp64-class Q limbs: everything that is left, summed over clients        k_qsum_fp
+void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uint32_t n_clients, uint32_t n_ct,
+                                  uint32_t nl) {
     const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, nparts = ps_.num_parts(nl), D = ps_.D;
     const size_t ct_words = (size_t)2 * nl * n, evk_words = (size_t)ps_.beta * 2 * D * n;
-    const bool fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0 && row_sum_supported(tabs_);
-    if (!fused) {  // ring sizes without the fused sum kernel: plain loop with the accumulating tail
-        for (uint32_t c = 0; c < n_clients; ++c)
-            reencrypt(cts + (size_t)c * n_ct * ct_words, evks + (size_t)c * evk_words, out, n_ct, nl, c != 0);
-        return;
+    const u64 *pinv = p_inverse(nl), *pq = p_doubles();
+    unsigned long long fp_mask = 0, intq_mask = 0, p_mask = 0;
+    for (uint32_t i = 0; i < nl; ++i) (tabs_.h_fp_of[i] ? fp_mask : intq_mask) |= 1ull << i;
+    for (uint32_t i = nl; i < ext; ++i) p_mask |= 1ull << i;
+    const uint32_t n_intq = (uint32_t)__builtin_popcountll(intq_mask);
+    const uint32_t group = std::min(n_clients, knobs_.qsum_group);
+    for (uint32_t b0 = 0; b0 < n_ct; b0 += knobs_.chunk) {
+        const uint32_t cnt = std::min(knobs_.chunk, n_ct - b0);
+        for (uint32_t g0 = 0; g0 < n_clients; g0 += group) {
+            const uint32_t gc = std::min(group, n_clients - g0), items = gc * cnt;
+            const size_t w_coef = (size_t)items * nl * n, w_dig = (size_t)items * nparts * ext * n;
+            const size_t w_pc = (size_t)items * 2 * K * n, w_conv = (size_t)items * 2 * nl * n;
+            const size_t w_til = (size_t)items * 2 * n_intq * n;
+            u64 *ws = workspace(w_coef + w_dig + w_pc + w_conv + w_til);
+            u64 *coef = ws, *dig = coef + w_coef, *pc = dig + w_dig, *conv = pc + w_pc, *til = conv + w_conv;
+            const u64 *ct0 = cts + ((size_t)g0 * n_ct + b0) * ct_words;  // client g0, index b0
+            const u64 *c1 = ct0 + (size_t)nl * n, *evk0 = evks + (size_t)g0 * evk_words;
+            const size_t ct_cstride = (size_t)n_ct * ct_words;
+            {   // ModUp of every item's c1: column-passed converted limbs; the row passes happen in the consumers
+                struct Reset {
+                    bool &flag;
+                    ~Reset() { flag = false; }
+                } reset{skip_rows_};
+                skip_rows_ = true;
+                modup_core(c1, ct_words, coef, dig, items, nl, true, cnt, ct_cstride);
+            }
+            InnerArgs ia{dig, c1, evk0, til, ct_words, nl, ext, D, ps_.alpha, items, 0, 0};
+            ia.ipc = cnt;
+            ia.c1_gstride = ct_cstride;
+            ia.evk_cstride = evk_words;
+            {   // P limbs: accumulators straight through the inverse row pass into pc
+                InnerArgs ap = ia;
+                ap.slot_mask = p_mask;
+                ap.nsel = K;
+                launch_row3_inner_int_k<2, true>(ap, tabs_, nparts, ps_.L, pc, K, stream_);
+            }
+            moddown_convert(nullptr, pc, conv, 2 * items, nl, true);
+            if (n_intq) {  // integer-class Q limbs: accumulators through a compact til, then the fused tail + sum
+                InnerArgs aq = ia;
+                aq.slot_mask = intq_mask;
+                aq.nsel = n_intq;
+                aq.til_compact = 1;
+                launch_row3_inner_int_k<2, false>(aq, tabs_, nparts, ps_.L, nullptr, K, stream_);
+                SumArgs sa{conv, til, ct0, out + (size_t)b0 * ct_words, pinv, pinv + nl,
+                           (size_t)cnt * 2 * nl * n, (size_t)cnt * 2 * n_intq * n, ct_cstride, ct_words,
+                           gc, nl, n_intq, 2 * cnt, 0, 0, g0 != 0 ? 1u : 0u};
+                sa.til_compact = 1;
+                launch_row_tail_sum<4>(sa, tabs_, true, stream_, 1u);
+            }
+            QSumArgs qa{dig, conv, ct0, evk0, out + (size_t)b0 * ct_words, pq, ct_cstride, ct_words, evk_words, ct_words,
+                        gc, cnt, nl, ext, D, ps_.alpha, fp_mask, (uint32_t)__builtin_popcountll(fp_mask), g0 != 0 ? 1u : 0u};
+            launch_qsum_fp<4>(qa, tabs_, nparts, stream_);
+            MK_HIP(hipGetLastError());
+        }
     }
+}
+
+// per-client flow: everything up to the column pass of ModDown runs per client (two clients in flight on two streams),
+// the last row pass + tail + sum is one kernel over all clients (k_row_tail_sum / k_row_tail_sum2 / k_row3_tail_sum)
+void Engine::reencrypt_sum_lanes(const u64 *cts, const u64 *evks, u64 *out, uint32_t n_clients, uint32_t n_ct, uint32_t nl) {
+    const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, nparts = ps_.num_parts(nl), D = ps_.D;
+    const size_t ct_words = (size_t)2 * nl * n, evk_words = (size_t)ps_.beta * 2 * D * n;
     const u64 *pinv = p_inverse(nl);
     const int log_h = fast_row(tabs_.log_r2, 1u << tabs_.log_r1);  // 9: three-round kernels on 512-point rows
-    for (uint32_t b0 = 0; b0 < n_ct; b0 += chunk_) {
-        const uint32_t cnt = n_ct - b0 < chunk_ ? n_ct - b0 : chunk_;
+    for (uint32_t b0 = 0; b0 < n_ct; b0 += knobs_.chunk) {
+        const uint32_t cnt = n_ct - b0 < knobs_.chunk ? n_ct - b0 : knobs_.chunk;
         // arena: per client {til, conv}; per lane {coef, dig, pc}
         const size_t w_til = (size_t)cnt * 2 * ext * n, w_conv = (size_t)cnt * 2 * nl * n;
         const size_t w_coef = (size_t)cnt * nl * n, w_dig = (size_t)cnt * nparts * ext * n, w_pc = (size_t)cnt * 2 * K * n;
         const size_t w_lane = w_coef + w_dig + w_pc;
-        // two clients in flight on two streams (MKCKKS_SUM_ONE_LANE=1 serialises them, e.g. to compare the HIP-event
-        // step time with the sum of rocprof kernel durations)
-        static const bool one_lane = [] { const char *e = std::getenv("MKCKKS_SUM_ONE_LANE"); return e && std::atoi(e) == 1; }();
-        const bool two = side_stream_ != nullptr && n_clients > 1 && !one_lane;
-        // clients in flight at once, each on its own stream with its own {coef, dig, pc} arena
-        static const uint32_t lanes_env = [] { const char *e = std::getenv("MKCKKS_SUM_LANES"); return e ? (uint32_t)std::atoi(e) : 2u; }();
-        const uint32_t n_lanes = !two ? 1u : std::min<uint32_t>(std::min<uint32_t>(std::max(lanes_env, 2u), MAX_SUM_LANES), n_clients);
+        // two clients in flight on two streams (Knobs::one_lane serialises them, e.g. to compare the HIP-event step time
+        // with the sum of rocprof kernel durations); 3 and 4 lanes were measured slower (-1.5 % / -5 %)
+        const uint32_t n_lanes = (side_stream_ != nullptr && n_clients > 1 && !knobs_.one_lane) ? 2u : 1u;
         u64 *ws = workspace((size_t)n_clients * (w_til + w_conv) + (size_t)n_lanes * w_lane);
         u64 *til0 = ws, *conv0 = til0 + (size_t)n_clients * w_til, *lane0 = conv0 + (size_t)n_clients * w_conv;
         hipStream_t main = stream_;
@@ -1446,73 +1494,55 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
             hipStream_t &ref, saved;
             ~Restore() { ref = saved; }
         } restore{stream_, main};
-        // Lanes: clients alternate between `main` and the side stream; the fused sum kernels of finished client
-        // groups run on a third stream so that this latency-bound kernel overlaps the next group's key switching.
-        static const uint32_t group_env = [] { const char *e = std::getenv("MKCKKS_SUM_GROUP"); return e ? (uint32_t)std::atoi(e) : 0u; }();
-        // clients per sum launch: measured on MI355X, one sum over all clients (15.9-16.1 k ct/s) beats sums of 4
-        // (15.7-15.9 k) or 2 (15.5 k) clients overlapped with the next group's key switching
-        const uint32_t group = (two && group_env) ? group_env : n_clients;
-        hipStream_t sum_stream = two ? sum_stream_ : main;
-        hipStream_t lane_stream[MAX_SUM_LANES] = {main, side_stream_, extra_lane_[0], extra_lane_[1]};
-        if (two) {
+        hipStream_t lane_stream[2] = {main, side_stream_};
+        if (n_lanes == 2) {
             MK_HIP(hipEventRecord(ev_fork_, main));
-            for (uint32_t l = 1; l < n_lanes; ++l) MK_HIP(hipStreamWaitEvent(lane_stream[l], ev_fork_, 0));
-            MK_HIP(hipStreamWaitEvent(sum_stream_, ev_fork_, 0));
+            MK_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
         }
-        for (uint32_t c0 = 0; c0 < n_clients; c0 += group) {
-            const uint32_t gcnt = std::min(group, n_clients - c0);
-            for (uint32_t c = c0; c < c0 + gcnt; ++c) {
-                const uint32_t lane = c % n_lanes;
-                stream_ = lane_stream[lane];  // the helpers below launch on stream_
-                cur_lane_ = lane;
-                u64 *coef = lane0 + (size_t)lane * w_lane, *dig = coef + w_coef, *pc = dig + w_dig;
-                u64 *til = til0 + (size_t)c * w_til, *conv = conv0 + (size_t)c * w_conv;
-                const u64 *ct = cts + ((size_t)c * n_ct + b0) * ct_words, *evk = evks + (size_t)c * evk_words;
-                const u64 *c1 = ct + (size_t)nl * n;
-                const bool p_rows = keyswitch_digits(c1, ct_words, evk, coef, dig, til, pc, cnt, nl);
-                // ModDown up to the column pass of the converted limbs
-                moddown_convert(til, pc, conv, 2 * cnt, nl, p_rows);
-            }
-            stream_ = main;
-            cur_lane_ = 0;
-            if (two) {  // the group's sum waits for every lane; the lanes go on with the next group
-                for (uint32_t l = 0; l < n_lanes; ++l) {
-                    MK_HIP(hipEventRecord(ev_lane_[l], lane_stream[l]));
-                    MK_HIP(hipStreamWaitEvent(sum_stream_, ev_lane_[l], 0));
-                }
-            }
-            SumArgs a{conv0 + (size_t)c0 * w_conv, til0 + (size_t)c0 * w_til,
-                      cts + ((size_t)c0 * n_ct + b0) * ct_words, out + (size_t)b0 * ct_words, pinv, pinv + nl,
-                      w_conv, w_til, (size_t)n_ct * ct_words, ct_words, gcnt, nl, ext, 2 * cnt, 0, 0, c0 != 0 ? 1u : 0u};
-            // the integer and the fp64 instance of the sum touch disjoint limbs: side by side on two streams
-            const char *sf = std::getenv("MKCKKS_SUM_FORK");
-            const bool sum_fork = two && sf && std::atoi(sf) != 0;  // measured: no gain, off
-            hipStream_t sum_int = sum_stream;
-            if (sum_fork) {
-                sum_int = aux_stream_[0];
-                MK_HIP(hipEventRecord(ev_a_, sum_stream));
-                MK_HIP(hipStreamWaitEvent(sum_int, ev_a_, 0));
-            }
-            switch (log_h) {
-                case 9: launch_row3_tail_sum<3>(a, tabs_, sum_stream, sum_int); break;
-                case 4:
-                    if (three_round_256()) launch_row3_tail_sum<2>(a, tabs_, sum_stream, sum_int);
-                    else launch_row_tail_sum<4>(a, tabs_, ps_.L, sum_stream, sum_int);
-                    break;
-                case 3: launch_row_tail_sum<3>(a, tabs_, ps_.L, sum_stream, sum_int); break;
-                default: launch_row_tail_sum<2>(a, tabs_, ps_.L, sum_stream, sum_int); break;
-            }
-            if (sum_fork) {
-                MK_HIP(hipEventRecord(ev_b_, sum_int));
-                MK_HIP(hipStreamWaitEvent(sum_stream, ev_b_, 0));
-            }
-            MK_HIP(hipGetLastError());
+        for (uint32_t c = 0; c < n_clients; ++c) {
+            const uint32_t lane = c % n_lanes;
+            stream_ = lane_stream[lane];  // the helpers below launch on stream_
+            u64 *coef = lane0 + (size_t)lane * w_lane, *dig = coef + w_coef, *pc = dig + w_dig;
+            u64 *til = til0 + (size_t)c * w_til, *conv = conv0 + (size_t)c * w_conv;
+            const u64 *ct = cts + ((size_t)c * n_ct + b0) * ct_words, *evk = evks + (size_t)c * evk_words;
+            const u64 *c1 = ct + (size_t)nl * n;
+            const bool p_rows = keyswitch_digits(c1, ct_words, evk, coef, dig, til, pc, cnt, nl);
+            // ModDown up to the column pass of the converted limbs
+            moddown_convert(til, pc, conv, 2 * cnt, nl, p_rows);
         }
-        if (two) {  // everything the side streams did is ordered before whatever follows on `main`
-            MK_HIP(hipEventRecord(ev_join_, sum_stream_));
+        stream_ = main;
+        if (n_lanes == 2) {  // the sum waits for the side lane
+            MK_HIP(hipEventRecord(ev_join_, side_stream_));
             MK_HIP(hipStreamWaitEvent(main, ev_join_, 0));
         }
+        SumArgs a{conv0, til0, cts + (size_t)b0 * ct_words, out + (size_t)b0 * ct_words, pinv, pinv + nl,
+                  w_conv, w_til, (size_t)n_ct * ct_words, ct_words, n_clients, nl, ext, 2 * cnt, 0, 0, 0u};
+        switch (log_h) {
+            case 9: launch_row3_tail_sum<3>(a, tabs_, main); break;
+            case 4:
+                if (knobs_.row3x) launch_row3_tail_sum<2>(a, tabs_, main);
+                else launch_row_tail_sum<4>(a, tabs_, knobs_.sum_pair, main);
+                break;
+            case 3: launch_row_tail_sum<3>(a, tabs_, knobs_.sum_pair, main); break;
+            default: launch_row_tail_sum<2>(a, tabs_, knobs_.sum_pair, main); break;
+        }
+        MK_HIP(hipGetLastError());
     }
+}
+
+void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n_clients, uint32_t n_ct, uint32_t nl) {
+    need_device();
+    check_nl(nl);
+    if (!n_clients || !n_ct) return;
+    const size_t ct_words = (size_t)2 * nl * ps_.n, evk_words = (size_t)ps_.beta * 2 * ps_.D * ps_.n;
+    const bool fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0 && row_sum_supported(tabs_);
+    if (!fused) {  // ring sizes without the fused sum kernel: plain loop with the accumulating tail
+        for (uint32_t c = 0; c < n_clients; ++c)
+            reencrypt(cts + (size_t)c * n_ct * ct_words, evks + (size_t)c * evk_words, out, n_ct, nl, c != 0);
+        return;
+    }
+    if (qsum_ok(nl)) reencrypt_sum_merged(cts, evks, out, n_clients, n_ct, nl);
+    else reencrypt_sum_lanes(cts, evks, out, n_clients, n_ct, nl);
 }
 
 void Engine::reencrypt(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl, bool accumulate) {
@@ -1520,8 +1550,8 @@ void Engine::reencrypt(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, u
     check_nl(nl);
     if (accumulate && ct == out) throw std::invalid_argument("accumulating re-encryption cannot run in place");
     const size_t ct_stride = (size_t)2 * nl * ps_.n;
-    for (uint32_t done = 0; done < n_ct; done += chunk_) {
-        const uint32_t cnt = n_ct - done < chunk_ ? n_ct - done : chunk_;
+    for (uint32_t done = 0; done < n_ct; done += knobs_.chunk) {
+        const uint32_t cnt = n_ct - done < knobs_.chunk ? n_ct - done : knobs_.chunk;
         reencrypt_chunk(ct + done * ct_stride, evk, out + done * ct_stride, cnt, nl, accumulate);
     }
 }

@@ -45,10 +45,27 @@ struct DevConv {
     const double *hatq_d;  // device, [n_in][n_out]: [S/s_i]_t / t
 };
 
-// the stream pair a pass is launched on (integer instance on `main`, fp64 instance on `side` when both have work)
+// the stream a pass is launched on
 struct Lanes {
-    hipStream_t main = nullptr, side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipStream_t main = nullptr;
+};
+
+// Switches of the library (environment variables MKCKKS_*), read once when a context is created.  Defaults are the
+// measured best; every non-default value has a parity test (tests/test_gpu_parity.py).
+struct Knobs {
+    uint32_t chunk = 16;         // MKCKKS_CHUNK: ciphertexts per workspace chunk
+    uint32_t qsum_group = 8;     // MKCKKS_QSUM_GROUP: clients per pass of the merged n-client flow
+    bool generic_ntt = false;    // MKCKKS_GENERIC_NTT=1: LDS-stage kernels for both passes
+    bool no_fp64 = false;        // MKCKKS_NO_FP64=1: integer arithmetic on every limb
+    bool fuse_inner = true;      // MKCKKS_FUSE_INNER=0: separate row pass + inner product (all limbs)
+    bool fuse_inner_int = true;  // MKCKKS_FUSE_INNER_INT=0: ... for the integer limbs only
+    bool fuse_p_inverse = true;  // MKCKKS_FUSE_P_INVERSE=0: P-limb accumulators through HBM
+    bool sum_pair = true;        // MKCKKS_SUM_PAIR=0: one client per iteration in the fused sum kernel
+    bool row3x = false;          // MKCKKS_ROW3X=1: three-round 8x8x4 fused kernels on 256-point rows
+    bool one_lane = false;       // MKCKKS_SUM_ONE_LANE=1: one client lane (kernels strictly serial)
+    bool conv_fp = true;         // MKCKKS_CONV_FP=0: conversion sources always as packed 30-bit halves
+    bool qsum = true;            // MKCKKS_QSUM=0: per-client key switch + k_row_tail_sum instead of the merged flow
+    static Knobs from_env();
 };
 
 class Engine {
@@ -117,7 +134,11 @@ private:
     const u64 *folded_scale(uint32_t nl);
     const u64 *p_inverse(uint32_t nl);
     void modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, uint32_t cnt, uint32_t nl,
-                    bool rows_int_only = false, hipEvent_t conv_done = nullptr);
+                    bool rows_int_only = false, uint32_t in_group = 0, size_t in_gstride = 0);
+    bool qsum_ok(uint32_t nl) const;
+    void reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uint32_t n_clients, uint32_t n_ct, uint32_t nl);
+    void reencrypt_sum_lanes(const u64 *cts, const u64 *evks, u64 *out, uint32_t n_clients, uint32_t n_ct, uint32_t nl);
+    const u64 *p_doubles();
     // returns true when the inverse ROW pass of the P limbs was done on the fly into `pc` (ModDown then starts with
     // the inverse column pass)
     bool keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u64 *coef, u64 *dig, u64 *til, u64 *pc,
@@ -135,26 +156,16 @@ private:
     u64 *d_tw_ = nullptr, *d_tw_sh_ = nullptr, *d_itw_ = nullptr, *d_itw_sh_ = nullptr;
     u64 *d_twb_ = nullptr, *d_itwb_ = nullptr;  // packed round-B tables of the row kernels (NttTables::twb)
     std::vector<uint8_t> fp_of_;  // per limb id: 1 = fp64 kernel instance
-    hipStream_t side_stream_ = nullptr;  // second lane for the fp64 instances of a pass
-    hipStream_t sum_stream_ = nullptr;   // fused sum kernels of finished client groups (reencrypt_sum)
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_a_ = nullptr, ev_b_ = nullptr;
-    static constexpr int MAX_SUM_LANES = 4;  // client lanes of reencrypt_sum: main, side_stream_, extra_lane_[0..1]
-    hipStream_t extra_lane_[MAX_SUM_LANES - 2] = {nullptr, nullptr};
-    hipEvent_t ev_lane_[MAX_SUM_LANES] = {nullptr, nullptr, nullptr, nullptr};
-    // per client lane: the fp64 fused inner product runs beside the integer row pass + inner product (independent limbs)
-    hipStream_t aux_stream_[MAX_SUM_LANES] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_conv_[MAX_SUM_LANES] = {nullptr, nullptr, nullptr, nullptr}, ev_aux_[MAX_SUM_LANES] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t cur_lane_ = 0;
+    hipStream_t side_stream_ = nullptr;  // second client lane of reencrypt_sum
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     bool skip_rows_ = false;  // modup_core: leave the row pass of the converted digits to the fused kernels
-    bool two_lanes_ = false;
     uint32_t *d_rot_ = nullptr;
     void *d_ksi_ = nullptr;
     u64 *ws_ = nullptr;
     size_t ws_words_ = 0;
-    uint32_t chunk_ = 16;  // ciphertexts per key-switch launch group (MKCKKS_CHUNK overrides)
+    Knobs knobs_;
     std::map<std::pair<uint32_t, uint32_t>, DevConv> modup_cache_;
     std::map<uint32_t, DevConv> moddown_cache_;
-    bool conv_fp_ = true;  // MKCKKS_CONV_FP=0: conversion sources always as packed 30-bit halves
     std::map<std::string, u64 *> vec_cache_;
     std::vector<void *> owned_;
 };

@@ -58,7 +58,16 @@ struct NttIo {
     // only: bit b of slot_mask = slot (in_slot0 + b) belongs to this launch, nsel = popcount(slot_mask)
     unsigned long long slot_mask = ~0ull;
     uint32_t nsel = 0;
+    // two-level input addressing (inverse row pass of the n-client flow, whose polynomials are the c1 of
+    // cts[client][index]): polynomial p is read at in + (p / in_group) * in_gstride + (p % in_group) * in_stride;
+    // in_group == 0: plain in + p * in_stride
+    uint32_t in_group = 0;
+    size_t in_gstride = 0;
 };
+MK_D size_t ntt_in_offset(const NttIo &io, uint32_t poly) {
+    return io.in_group ? (size_t)(poly / io.in_group) * io.in_gstride + (size_t)(poly % io.in_group) * io.in_stride
+                       : (size_t)poly * io.in_stride;
+}
 
 MK_D uint32_t nth_set_bit(unsigned long long mask, uint32_t n) {
     for (uint32_t i = 0; i < n; ++i) mask &= mask - 1;

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
     if ((lc.fp != 0) != FP) return;  // block-uniform
     const uint32_t row0 = (grp % tiles) * S;
     const int g = threadIdx.x / H, j = threadIdx.x % H;
-    const u64 *src = io.in + (size_t)poly * io.in_stride + (size_t)(io.in_slot0 + sl) * n + (size_t)row0 * R;
+    const u64 *src = io.in + ntt_in_offset(io, poly) + (size_t)(io.in_slot0 + sl) * n + (size_t)row0 * R;
     u64 *dst = io.out + (size_t)poly * io.out_stride + (size_t)(io.out_slot0 + sl) * n + (size_t)row0 * R;
     const u64 *tw = (INV ? T.itw : T.tw) + (size_t)id * n;
     const u64 *tw_sh = (INV ? T.itw_sh : T.tw_sh) + (size_t)id * n;
@@ -643,6 +643,7 @@ struct SumArgs {
     unsigned long long slot_mask;
     uint32_t nsel;
     uint32_t init_from_out;  // continue a running sum: the accumulators start from `out` instead of zero
+    uint32_t til_compact = 0;  // til holds only this launch's slots: [client][poly][nsel][N], slot index = rank in slot_mask
 };
 template <int LOG_H, bool FP, int WAVES>
 __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, NttTables T) {
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
     for (int i = 0; i < PAIRS; ++i)
         acc[i] = a.init_from_out ? reinterpret_cast<const ulong2 *>(dst)[wave_pair<LOG_H>(i)] : ulong2{0, 0};
     const u64 *src0 = a.conv + ((size_t)poly * a.nl + sl) * n + tile_off + (size_t)g * R + j;
-    const size_t til_off = ((size_t)poly * a.ext + sl) * n + tile_off;
+    const size_t til_off = ((size_t)poly * a.ext + (a.til_compact ? grp / tiles : sl)) * n + tile_off;
     const size_t ct_off = (size_t)(poly >> 1) * a.ct_stride + (size_t)sl * n + tile_off;
     const bool with_c0 = (poly & 1) == 0;
     u64 xa[H], xb[H];
@@ -869,7 +870,17 @@ struct InnerArgs {
     uint32_t nl, ext, D, alpha, items;
     unsigned long long slot_mask;  // fp-class Q limbs
     uint32_t nsel;
+    // n-client flow: item = client * ipc + index; c1 of an item at c1 + client * c1_gstride + index * c1_stride, the
+    // client's key at evk + client * evk_cstride (ipc >= items: one client)
+    uint32_t ipc = 0xFFFFFFFFu;
+    size_t c1_gstride = 0, evk_cstride = 0;
+    // til with only this launch's slots: [item][2][nsel][N], slot index = rank in slot_mask
+    uint32_t til_compact = 0;
 };
+MK_D const u64 *inner_c1(const InnerArgs &a, uint32_t item) {
+    return a.c1 + (size_t)(item / a.ipc) * a.c1_gstride + (size_t)(item % a.ipc) * a.c1_stride;
+}
+MK_D const u64 *inner_evk(const InnerArgs &a, uint32_t item) { return a.evk + (size_t)(item / a.ipc) * a.evk_cstride; }
 template <int LOG_H, int NPARTS, int WAVES>
 __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a, NttTables T) {
     using TL = RowTile<LOG_H>;
@@ -1535,6 +1546,7 @@ __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_
     u64 wc[7], wpc[7];
     row3_load_c_twiddles<LOGC>(tw, tw_sh, r1 + row0 + c.g, c.t, wc, wpc);
     const size_t tile_off = (size_t)row0 * R;
+    const u64 *evk = inner_evk(a, item);
     int jn = own == 0 ? 1 : 0;
     const u64 *dig0 = a.dig + ((size_t)item * NPARTS * a.ext + sl) * n + tile_off + (size_t)c.g * R + c.t;
     u64 x[8];
@@ -1547,9 +1559,9 @@ __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_
 #pragma unroll
     for (int i = 0; i < 2 * PAIRS; ++i) h0[i] = l0[i] = h1[i] = l1[i] = 0;
     if (own >= 0) {  // the digit that owns this limb: c1 itself
-        const u64 *y0 = a.c1 + (size_t)item * a.c1_stride + (size_t)sl * n + tile_off;
-        const u64 *e0 = a.evk + (((size_t)own * 2 + 0) * a.D + id) * n + tile_off;
-        const u64 *e1 = a.evk + (((size_t)own * 2 + 1) * a.D + id) * n + tile_off;
+        const u64 *y0 = inner_c1(a, item) + (size_t)sl * n + tile_off;
+        const u64 *e0 = evk + (((size_t)own * 2 + 0) * a.D + id) * n + tile_off;
+        const u64 *e1 = evk + (((size_t)own * 2 + 1) * a.D + id) * n + tile_off;
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
             const int e = row3_pair<LOGC>(c.g, c.t, i);
@@ -1576,8 +1588,8 @@ __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_
             for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + TPR * k);
         }
         wave_lds_sync();
-        const u64 *e0 = a.evk + (((size_t)dj * 2 + 0) * a.D + id) * n + tile_off;
-        const u64 *e1 = a.evk + (((size_t)dj * 2 + 1) * a.D + id) * n + tile_off;
+        const u64 *e0 = evk + (((size_t)dj * 2 + 0) * a.D + id) * n + tile_off;
+        const u64 *e1 = evk + (((size_t)dj * 2 + 1) * a.D + id) * n + tile_off;
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
             const int e = row3_pair<LOGC>(c.g, c.t, i);
@@ -1611,7 +1623,8 @@ __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_
             res[i].y = NPARTS <= 4 ? reduce_sum4(hy, ly, lc) : reduce_wide(hy, ly, lc);
         }
         if (!inv) {
-            u64 *td = a.til + (((size_t)item * 2 + comp) * a.ext + sl) * n + tile_off;
+            u64 *td = a.til + (a.til_compact ? ((size_t)item * 2 + comp) * a.nsel + grp / tiles
+                                             : ((size_t)item * 2 + comp) * a.ext + sl) * n + tile_off;
 #pragma unroll
             for (int i = 0; i < PAIRS; ++i) st_stream2(reinterpret_cast<ulong2 *>(td) + row3_pair<LOGC>(c.g, c.t, i), res[i]);
         } else {

@@ -1,0 +1,205 @@
+// qsum_kernels.hpp -- the Q-limb half of the n-client server step in ONE kernel (gfx950, fp64-class limbs).
+//
+// For a (ciphertext index b, Q limb t, row tile) the workgroup walks ALL clients c and, per client,
+//   * finishes the forward transform (row pass) of every converted ModUp digit d_j[t] and accumulates the eval-key
+//     inner products  d_j[t] * b_j[t],  d_j[t] * a_j[t]   (EvalFastKeySwitchCoreExt; the digit that owns t is c1 itself),
+//   * finishes the forward transform of ApproxModDown's converted limbs conv_0[t], conv_1[t] and subtracts them,
+//   * adds c0 * P (component 0),
+// keeping the two running sums over digits AND clients in registers as exact doubles; after the last client one
+// multiplication by P^-1 gives  sum_c [ (ctilde_c - conv_c) * P^-1 (+ c0_c) ]  mod q_t, the coefficient-wise sum of the
+// clients' re-encryptions (ReEncrypt x n at changeCipherDomain.cpp:74 + the EvalAdd chain of
+// aggregateEncryptedWeights.cpp:82).  Everything between the products and the final canonical value is ring arithmetic
+// mod q_t, so the stored residues are those of the reference's per-client chain, bit for bit.
+//
+// Against k_row_inner_fp + k_row_tail_sum2 this removes the round trip of the key-switch accumulators over Q through
+// HBM (2 L limb writes + 2 L limb reads per client ciphertext) and n - 1 of the n multiplications by P^-1.
+#pragma once
+#include "ntt_radix.hpp"
+
+namespace mk {
+
+struct QSumArgs {
+    const u64 *dig;    // [client][cnt][nparts][ext][N] column-passed converted digits (doubles on fp64-class limbs)
+    const u64 *conv;   // [client][cnt][2][nl][N]       column-passed ModDown conversions
+    const u64 *cts;    // input ciphertexts: client c, index i at cts + c * ct_cstride + i * ct_stride, [2][nl][N]
+    const u64 *evk;    // client c at evk + c * evk_cstride: [nparts][2][D][N]
+    u64 *out;          // index i at out + i * ct_stride_out: [2][nl][N]
+    const u64 *pq;     // per Q limb t, 4 doubles: P mod q, (P mod q) / q, P^-1 mod q, (P^-1 mod q) / q
+    size_t ct_cstride, ct_stride, evk_cstride, out_stride;
+    uint32_t n_clients, cnt, nl, ext, D, alpha;
+    unsigned long long slot_mask;  // fp64-class Q limbs
+    uint32_t nsel;
+    uint32_t init_from_out;  // continue a running sum held in `out` (client groups)
+};
+
+template <int LOG_H, int NPARTS>
+__global__ __launch_bounds__(NTT_THREADS, 2) void k_qsum_fp(QSumArgs a, NttTables T) {
+    using TL = RowTile<LOG_H>;
+    using TA = RowTwA<LOG_H>;
+    constexpr int H = TL::H, S = TL::S, R = TL::R, PAIRS = S * R / 2 / NTT_THREADS;
+    constexpr int ND = NPARTS - 1;  // converted digits of a Q limb (every Q limb has an owning digit)
+    __shared__ u64 lds[TL::WORDS + 2 * TA::WORDS];
+    u64 *twa = lds + TL::WORDS, *twa_sh = twa + TA::WORDS;
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
+    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
+    uint32_t grp, b;
+    if (groups % 8 == 0) {  // the ciphertexts of one (limb, tile) share its eval-key and twiddle tiles: same XCD, consecutive
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / a.cnt) * 8 + xcd;
+        b = qidx % a.cnt;
+    } else {
+        grp = blockIdx.x / a.cnt;
+        b = blockIdx.x % a.cnt;
+    }
+    const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);  // Q limb: slot == limb id
+    const LimbConst lc = T.limb[sl];
+    const int own = (int)(sl / a.alpha);
+    const uint32_t row0 = (grp % tiles) * S;
+    const int g = threadIdx.x / H, j = threadIdx.x % H;
+    const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
+    const u64 *twb = T.twb + (size_t)sl * 2 * n;
+    const size_t tile_off = (size_t)row0 * R;
+    const double q = lc.qd, qinv = lc.qinv;
+    const double pm = bitsd(a.pq[4 * sl]), pmq = bitsd(a.pq[4 * sl + 1]);
+    stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);  // round-A twiddles: the same for every transform
+    u64 *o0 = a.out + (size_t)b * a.out_stride + (size_t)sl * n + tile_off;
+    u64 *o1 = o0 + (size_t)a.nl * n;
+    double2 acc0[PAIRS], acc1[PAIRS];
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+        if (a.init_from_out) {  // the stored sum carries the factor P^-1: put P back (exact, mod q)
+            const int e = wave_pair<LOG_H>(i);
+            const ulong2 v0 = reinterpret_cast<const ulong2 *>(o0)[e], v1 = reinterpret_cast<const ulong2 *>(o1)[e];
+            acc0[i].x = fp_mulmod(u52_to_double(v0.x), pm, pmq, q);
+            acc0[i].y = fp_mulmod(u52_to_double(v0.y), pm, pmq, q);
+            acc1[i].x = fp_mulmod(u52_to_double(v1.x), pm, pmq, q);
+            acc1[i].y = fp_mulmod(u52_to_double(v1.y), pm, pmq, q);
+        } else {
+            acc0[i] = double2{0.0, 0.0};
+            acc1[i] = double2{0.0, 0.0};
+        }
+    }
+    // transform u of client c: u < ND converted digits (owning digit skipped), then the two ModDown conversions
+    const size_t th_off = tile_off + (size_t)g * R + j;
+    auto src_of = [&](uint32_t c, int u) -> const u64 * {
+        const size_t item = (size_t)c * a.cnt + b;
+        if (u < ND) {
+            const int dj = u < own ? u : u + 1;
+            return a.dig + ((item * NPARTS + dj) * a.ext + sl) * n + th_off;
+        }
+        return a.conv + ((item * 2 + (u - ND)) * a.nl + sl) * n + th_off;
+    };
+    u64 x[H];
+    {
+        const u64 *src = src_of(0, 0);
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = ld_stream(src + H * k);
+    }
+#pragma unroll 1
+    for (uint32_t c = 0; c < a.n_clients; ++c) {
+        const u64 *ct = a.cts + (size_t)c * a.ct_cstride + (size_t)b * a.ct_stride + (size_t)sl * n + tile_off;
+        const u64 *ek = a.evk + (size_t)c * a.evk_cstride + (size_t)sl * n + tile_off;
+        {   // the digit that owns this limb: c1 itself (EVALUATION format); and c0 * P on component 0
+            const u64 *y1 = ct + (size_t)a.nl * n;
+            const u64 *e0 = ek + ((size_t)own * 2 + 0) * a.D * n, *e1 = ek + ((size_t)own * 2 + 1) * a.D * n;
+#pragma unroll
+            for (int i = 0; i < PAIRS; ++i) {
+                const int e = wave_pair<LOG_H>(i);
+                const ulong2 yy = ld_stream2(reinterpret_cast<const ulong2 *>(y1) + e);
+                const ulong2 zz = ld_stream2(reinterpret_cast<const ulong2 *>(ct) + e);
+                const ulong2 bb = reinterpret_cast<const ulong2 *>(e0)[e];
+                const ulong2 aa = reinterpret_cast<const ulong2 *>(e1)[e];
+                const double yx = u52_to_double(yy.x), yz = u52_to_double(yy.y);
+                acc0[i].x += fp_mulmod_any(yx, u52_to_double(bb.x), q, qinv) + fp_mulmod(u52_to_double(zz.x), pm, pmq, q);
+                acc0[i].y += fp_mulmod_any(yz, u52_to_double(bb.y), q, qinv) + fp_mulmod(u52_to_double(zz.y), pm, pmq, q);
+                acc1[i].x += fp_mulmod_any(yx, u52_to_double(aa.x), q, qinv);
+                acc1[i].y += fp_mulmod_any(yz, u52_to_double(aa.y), q, qinv);
+                if (NPARTS > 4) {  // keeps the sums below 2^53 for up to 6 digits (see the bound below)
+                    acc0[i].x = fp_reduce(acc0[i].x, q, qinv);
+                    acc0[i].y = fp_reduce(acc0[i].y, q, qinv);
+                    acc1[i].x = fp_reduce(acc1[i].x, q, qinv);
+                    acc1[i].y = fp_reduce(acc1[i].y, q, qinv);
+                }
+            }
+        }
+#pragma unroll 1
+        for (int u = 0; u < ND + 2; ++u) {
+            {
+                u64 w[H - 1], wp[H - 1];
+                wave_lds_sync();  // twiddles staged (first transform) / previous transform's consumers finished with LDS
+                TA::fetch(twa, twa_sh, g, w, wp);
+                radix_forward_fp<LOG_H>(x, w, wp, q, qinv);
+            }
+            u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
+            load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
+#pragma unroll
+            for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
+            radix_forward_fp<LOG_H>(x, w2, wp2, q, qinv);
+#pragma unroll
+            for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));  // |y| <= 0.51 q
+            {   // the next transform's inputs are requested while this one's results are consumed
+                const bool last_u = u == ND + 1;
+                if (!last_u || c + 1 < a.n_clients) {
+                    const u64 *src = last_u ? src_of(c + 1, 0) : src_of(c, u + 1);
+#pragma unroll
+                    for (int k = 0; k < H; ++k) x[k] = ld_stream(src + H * k);
+                }
+            }
+            wave_lds_sync();
+            if (u < ND) {
+                const int dj = u < own ? u : u + 1;
+                const u64 *e0 = ek + ((size_t)dj * 2 + 0) * a.D * n, *e1 = ek + ((size_t)dj * 2 + 1) * a.D * n;
+#pragma unroll
+                for (int i = 0; i < PAIRS; ++i) {
+                    const int e = wave_pair<LOG_H>(i);
+                    const int gg = (2 * e) / R, xx = (2 * e) % R;
+                    const ulong2 bb = reinterpret_cast<const ulong2 *>(e0)[e];
+                    const ulong2 aa = reinterpret_cast<const ulong2 *>(e1)[e];
+                    const double yx = bitsd(lds[TL::at(gg, xx)]), yz = bitsd(lds[TL::at(gg, xx + 1)]);
+                    acc0[i].x += fp_mulmod_any(yx, u52_to_double(bb.x), q, qinv);
+                    acc0[i].y += fp_mulmod_any(yz, u52_to_double(bb.y), q, qinv);
+                    acc1[i].x += fp_mulmod_any(yx, u52_to_double(aa.x), q, qinv);
+                    acc1[i].y += fp_mulmod_any(yz, u52_to_double(aa.y), q, qinv);
+                }
+            } else if (u == ND) {
+#pragma unroll
+                for (int i = 0; i < PAIRS; ++i) {
+                    const int e = wave_pair<LOG_H>(i);
+                    const int gg = (2 * e) / R, xx = (2 * e) % R;
+                    acc0[i].x -= bitsd(lds[TL::at(gg, xx)]);
+                    acc0[i].y -= bitsd(lds[TL::at(gg, xx + 1)]);
+                }
+            } else {
+                // per client the sums grow by at most 0.97 q (own digit) + 0.82 q (c0 P) + 0.75 q per converted digit +
+                // 0.51 q (conversion) on top of the 0.51 q carried over: < 4.4 q < 2^53 for up to 4 digits (5, 6 digits:
+                // the extra reduction above); one reduction per client brings them back to 0.51 q
+#pragma unroll
+                for (int i = 0; i < PAIRS; ++i) {
+                    const int e = wave_pair<LOG_H>(i);
+                    const int gg = (2 * e) / R, xx = (2 * e) % R;
+                    acc1[i].x = fp_reduce(acc1[i].x - bitsd(lds[TL::at(gg, xx)]), q, qinv);
+                    acc1[i].y = fp_reduce(acc1[i].y - bitsd(lds[TL::at(gg, xx + 1)]), q, qinv);
+                    acc0[i].x = fp_reduce(acc0[i].x, q, qinv);
+                    acc0[i].y = fp_reduce(acc0[i].y, q, qinv);
+                }
+            }
+        }
+    }
+    const double pi = bitsd(a.pq[4 * sl + 2]), piq = bitsd(a.pq[4 * sl + 3]);
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+        const int e = wave_pair<LOG_H>(i);
+        ulong2 r0, r1v;
+        r0.x = fp_to_canonical(fp_mulmod(acc0[i].x, pi, piq, q), q, qinv);
+        r0.y = fp_to_canonical(fp_mulmod(acc0[i].y, pi, piq, q), q, qinv);
+        r1v.x = fp_to_canonical(fp_mulmod(acc1[i].x, pi, piq, q), q, qinv);
+        r1v.y = fp_to_canonical(fp_mulmod(acc1[i].y, pi, piq, q), q, qinv);
+        reinterpret_cast<ulong2 *>(o0)[e] = r0;
+        reinterpret_cast<ulong2 *>(o1)[e] = r1v;
+    }
+}
+
+}  // namespace mk

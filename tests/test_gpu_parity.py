@@ -383,6 +383,10 @@ def test_reencrypt_sum(ctxs, name, nl, C, B):
                                  {"MKCKKS_FUSE_INNER_INT": "0"},  # integer limbs: separate row pass + inner product
                                  {"MKCKKS_FUSE_P_INVERSE": "0"},  # P limbs: accumulators to HBM, separate inverse row pass
                                  {"MKCKKS_CONV_FP": "0"},         # conversion sources as packed 30-bit halves for every target
+                                 {"MKCKKS_QSUM": "0"},            # per-client key switch on two lanes + k_row_tail_sum2
+                                 {"MKCKKS_QSUM": "0", "MKCKKS_SUM_ONE_LANE": "1"},
+                                 {"MKCKKS_QSUM_GROUP": "2"},      # merged flow, clients in groups of 2 (running sum in out)
+                                 {"MKCKKS_QSUM_GROUP": "1"},
                                  {"MKCKKS_SUM_ONE_LANE": "1"}])   # clients strictly one after the other
 def test_unfused_kernel_paths_stay_bit_exact(ctxs, monkeypatch, env):
     """Every non-default kernel path the library keeps behind a switch (other ring sizes fall back to them, A/B

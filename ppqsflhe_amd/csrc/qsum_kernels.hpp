@@ -18,6 +18,13 @@
 
 namespace mk {
 
+#ifndef MK_QSUM_XN
+#define MK_QSUM_XN 0  // 1: inputs of transform u+1 requested before transform u starts (32 more registers): measured -0.5 %
+#endif
+#ifndef MK_QSUM_TWREG
+#define MK_QSUM_TWREG 1
+#endif
+
 struct QSumArgs {
     const u64 *dig;    // [client][cnt][nparts][ext][N] column-passed converted digits (doubles on fp64-class limbs)
     const u64 *conv;   // [client][cnt][2][nl][N]       column-passed ModDown conversions
@@ -89,6 +96,11 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_qsum_fp(QSumArgs a, NttTable
         }
         return a.conv + ((item * 2 + (u - ND)) * a.nl + sl) * n + th_off;
     };
+    // round-B twiddles of this thread: the same for every transform of the kernel (one limb, one row); with
+    // MK_QSUM_TWREG they stay in registers instead of being re-read from L2 per transform (60 registers against
+    // 15 x 16-byte loads per transform)
+    u64 w2[H - 1], wp2[H - 1];
+    if (MK_QSUM_TWREG) load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
     u64 x[H];
     {
         const u64 *src = src_of(0, 0);
@@ -124,14 +136,24 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_qsum_fp(QSumArgs a, NttTable
         }
 #pragma unroll 1
         for (int u = 0; u < ND + 2; ++u) {
+            // the NEXT transform's inputs are requested before this one starts: their latency runs under two rounds of
+            // butterflies and the products (two transforms' inputs are in registers at a time)
+            u64 xn[H];
+            if (MK_QSUM_XN) {
+                const bool last_u = u == ND + 1;
+                if (!last_u || c + 1 < a.n_clients) {
+                    const u64 *src = last_u ? src_of(c + 1, 0) : src_of(c, u + 1);
+#pragma unroll
+                    for (int k = 0; k < H; ++k) xn[k] = ld_stream(src + H * k);
+                }
+            }
             {
                 u64 w[H - 1], wp[H - 1];
                 wave_lds_sync();  // twiddles staged (first transform) / previous transform's consumers finished with LDS
                 TA::fetch(twa, twa_sh, g, w, wp);
                 radix_forward_fp<LOG_H>(x, w, wp, q, qinv);
             }
-            u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
-            load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
+            if (!MK_QSUM_TWREG) load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);  // requested before the exchange
 #pragma unroll
             for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
             wave_lds_sync();
@@ -140,7 +162,10 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_qsum_fp(QSumArgs a, NttTable
             radix_forward_fp<LOG_H>(x, w2, wp2, q, qinv);
 #pragma unroll
             for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));  // |y| <= 0.51 q
-            {   // the next transform's inputs are requested while this one's results are consumed
+            if (MK_QSUM_XN) {
+#pragma unroll
+                for (int k = 0; k < H; ++k) x[k] = xn[k];
+            } else {  // requested while this transform's results are consumed
                 const bool last_u = u == ND + 1;
                 if (!last_u || c + 1 < a.n_clients) {
                     const u64 *src = last_u ? src_of(c + 1, 0) : src_of(c, u + 1);
@@ -192,6 +217,168 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_qsum_fp(QSumArgs a, NttTable
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
         const int e = wave_pair<LOG_H>(i);
+        ulong2 r0, r1v;
+        r0.x = fp_to_canonical(fp_mulmod(acc0[i].x, pi, piq, q), q, qinv);
+        r0.y = fp_to_canonical(fp_mulmod(acc0[i].y, pi, piq, q), q, qinv);
+        r1v.x = fp_to_canonical(fp_mulmod(acc1[i].x, pi, piq, q), q, qinv);
+        r1v.y = fp_to_canonical(fp_mulmod(acc1[i].y, pi, piq, q), q, qinv);
+        reinterpret_cast<ulong2 *>(o0)[e] = r0;
+        reinterpret_cast<ulong2 *>(o1)[e] = r1v;
+    }
+}
+
+// The same kernel on the three-round row geometry (RowT<LOGC>: 8 words per thread, 256-point rows as 8 x 8 x 4): the
+// accumulators are 32 registers instead of 64, every twiddle of the limb's rows is staged once (rounds A, B in LDS,
+// round C in 28 registers) instead of being re-read from L2 per transform, and the kernel runs 3-4 waves per SIMD.
+template <int NPARTS, int LOGC, int MINW>
+__global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttTables T) {
+    using TL = RowT<LOGC>;
+    constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
+    constexpr int ND = NPARTS - 1;
+    __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
+    Row3Ctx c;
+    c.lds = lds;
+    c.twa = lds + TL::WORDS;
+    c.twa_sh = c.twa + TL::TWA;
+    c.twb = c.twa_sh + TL::TWA;
+    c.twb_sh = c.twb + TL::TWB;
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
+    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
+    uint32_t grp, b;
+    if (groups % 8 == 0) {
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / a.cnt) * 8 + xcd;
+        b = qidx % a.cnt;
+    } else {
+        grp = blockIdx.x / a.cnt;
+        b = blockIdx.x % a.cnt;
+    }
+    const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);
+    const LimbConst lc = T.limb[sl];
+    const int own = (int)(sl / a.alpha);
+    const uint32_t row0 = (grp % tiles) * S;
+    c.g = threadIdx.x / TPR;
+    c.t = threadIdx.x % TPR;
+    const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
+    row3_stage_twiddles<LOGC>(c, tw, tw_sh, r1 + row0);
+    u64 wc[7], wpc[7];
+    row3_load_c_twiddles<LOGC>(tw, tw_sh, r1 + row0 + c.g, c.t, wc, wpc);
+    const size_t tile_off = (size_t)row0 * R;
+    const double q = lc.qd, qinv = lc.qinv;
+    const double pm = bitsd(a.pq[4 * sl]), pmq = bitsd(a.pq[4 * sl + 1]);
+    u64 *o0 = a.out + (size_t)b * a.out_stride + (size_t)sl * n + tile_off;
+    u64 *o1 = o0 + (size_t)a.nl * n;
+    double2 acc0[PAIRS], acc1[PAIRS];
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+        if (a.init_from_out) {
+            const int e = row3_pair<LOGC>(c.g, c.t, i);
+            const ulong2 v0 = reinterpret_cast<const ulong2 *>(o0)[e], v1 = reinterpret_cast<const ulong2 *>(o1)[e];
+            acc0[i].x = fp_mulmod(u52_to_double(v0.x), pm, pmq, q);
+            acc0[i].y = fp_mulmod(u52_to_double(v0.y), pm, pmq, q);
+            acc1[i].x = fp_mulmod(u52_to_double(v1.x), pm, pmq, q);
+            acc1[i].y = fp_mulmod(u52_to_double(v1.y), pm, pmq, q);
+        } else {
+            acc0[i] = double2{0.0, 0.0};
+            acc1[i] = double2{0.0, 0.0};
+        }
+    }
+    const size_t th_off = tile_off + (size_t)c.g * R + c.t;
+    auto src_of = [&](uint32_t cl, int u) -> const u64 * {
+        const size_t item = (size_t)cl * a.cnt + b;
+        if (u < ND) {
+            const int dj = u < own ? u : u + 1;
+            return a.dig + ((item * NPARTS + dj) * a.ext + sl) * n + th_off;
+        }
+        return a.conv + ((item * 2 + (u - ND)) * a.nl + sl) * n + th_off;
+    };
+    u64 x[8];
+    {
+        const u64 *src = src_of(0, 0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + TPR * k);
+    }
+    __syncthreads();  // twiddles staged
+#pragma unroll 1
+    for (uint32_t cl = 0; cl < a.n_clients; ++cl) {
+        const u64 *ct = a.cts + (size_t)cl * a.ct_cstride + (size_t)b * a.ct_stride + (size_t)sl * n + tile_off;
+        const u64 *ek = a.evk + (size_t)cl * a.evk_cstride + (size_t)sl * n + tile_off;
+        {
+            const u64 *y1 = ct + (size_t)a.nl * n;
+            const u64 *e0 = ek + ((size_t)own * 2 + 0) * a.D * n, *e1 = ek + ((size_t)own * 2 + 1) * a.D * n;
+#pragma unroll
+            for (int i = 0; i < PAIRS; ++i) {
+                const int e = row3_pair<LOGC>(c.g, c.t, i);
+                const ulong2 yy = ld_stream2(reinterpret_cast<const ulong2 *>(y1) + e);
+                const ulong2 zz = ld_stream2(reinterpret_cast<const ulong2 *>(ct) + e);
+                const ulong2 bb = reinterpret_cast<const ulong2 *>(e0)[e];
+                const ulong2 aa = reinterpret_cast<const ulong2 *>(e1)[e];
+                const double yx = u52_to_double(yy.x), yz = u52_to_double(yy.y);
+                acc0[i].x += fp_mulmod_any(yx, u52_to_double(bb.x), q, qinv) + fp_mulmod(u52_to_double(zz.x), pm, pmq, q);
+                acc0[i].y += fp_mulmod_any(yz, u52_to_double(bb.y), q, qinv) + fp_mulmod(u52_to_double(zz.y), pm, pmq, q);
+                acc1[i].x += fp_mulmod_any(yx, u52_to_double(aa.x), q, qinv);
+                acc1[i].y += fp_mulmod_any(yz, u52_to_double(aa.y), q, qinv);
+                if (NPARTS > 4) {
+                    acc0[i].x = fp_reduce(acc0[i].x, q, qinv);
+                    acc0[i].y = fp_reduce(acc0[i].y, q, qinv);
+                    acc1[i].x = fp_reduce(acc1[i].x, q, qinv);
+                    acc1[i].y = fp_reduce(acc1[i].y, q, qinv);
+                }
+            }
+        }
+#pragma unroll 1
+        for (int u = 0; u < ND + 2; ++u) {
+            wave_lds_sync();  // previous transform's consumers finished reading this wave's rows
+            row3_forward<true, LOGC>(x, c, wc, wpc, lc);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 8 * c.t + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));
+            {
+                const bool last_u = u == ND + 1;
+                if (!last_u || cl + 1 < a.n_clients) {
+                    const u64 *src = last_u ? src_of(cl + 1, 0) : src_of(cl, u + 1);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + TPR * k);
+                }
+            }
+            wave_lds_sync();
+            if (u < ND) {
+                const int dj = u < own ? u : u + 1;
+                const u64 *e0 = ek + ((size_t)dj * 2 + 0) * a.D * n, *e1 = ek + ((size_t)dj * 2 + 1) * a.D * n;
+#pragma unroll
+                for (int i = 0; i < PAIRS; ++i) {
+                    const int e = row3_pair<LOGC>(c.g, c.t, i);
+                    const int xx = (2 * e) % R;
+                    const ulong2 bb = reinterpret_cast<const ulong2 *>(e0)[e];
+                    const ulong2 aa = reinterpret_cast<const ulong2 *>(e1)[e];
+                    const double yx = bitsd(lds[TL::at(c.g, xx)]), yz = bitsd(lds[TL::at(c.g, xx + 1)]);
+                    acc0[i].x += fp_mulmod_any(yx, u52_to_double(bb.x), q, qinv);
+                    acc0[i].y += fp_mulmod_any(yz, u52_to_double(bb.y), q, qinv);
+                    acc1[i].x += fp_mulmod_any(yx, u52_to_double(aa.x), q, qinv);
+                    acc1[i].y += fp_mulmod_any(yz, u52_to_double(aa.y), q, qinv);
+                }
+            } else if (u == ND) {
+#pragma unroll
+                for (int i = 0; i < PAIRS; ++i) {
+                    const int xx = (2 * row3_pair<LOGC>(c.g, c.t, i)) % R;
+                    acc0[i].x -= bitsd(lds[TL::at(c.g, xx)]);
+                    acc0[i].y -= bitsd(lds[TL::at(c.g, xx + 1)]);
+                }
+            } else {  // bounds: see k_qsum_fp
+#pragma unroll
+                for (int i = 0; i < PAIRS; ++i) {
+                    const int xx = (2 * row3_pair<LOGC>(c.g, c.t, i)) % R;
+                    acc1[i].x = fp_reduce(acc1[i].x - bitsd(lds[TL::at(c.g, xx)]), q, qinv);
+                    acc1[i].y = fp_reduce(acc1[i].y - bitsd(lds[TL::at(c.g, xx + 1)]), q, qinv);
+                    acc0[i].x = fp_reduce(acc0[i].x, q, qinv);
+                    acc0[i].y = fp_reduce(acc0[i].y, q, qinv);
+                }
+            }
+        }
+    }
+    const double pi = bitsd(a.pq[4 * sl + 2]), piq = bitsd(a.pq[4 * sl + 3]);
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+        const int e = row3_pair<LOGC>(c.g, c.t, i);
         ulong2 r0, r1v;
         r0.x = fp_to_canonical(fp_mulmod(acc0[i].x, pi, piq, q), q, qinv);
         r0.y = fp_to_canonical(fp_mulmod(acc0[i].y, pi, piq, q), q, qinv);

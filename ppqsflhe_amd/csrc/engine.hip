@@ -453,7 +453,7 @@ Knobs Knobs::from_env() {
     }
     if (const char *e = std::getenv("MKCKKS_QSUM_GEOM")) {
         const int v = std::atoi(e);
-        if (v == 2 || v == 3 || v == 4) k.qsum_geom = v;
+        if (v == 2 || v == 3) k.qsum_geom = v;
     }
     k.generic_ntt = env_flag("MKCKKS_GENERIC_NTT", k.generic_ntt);
     k.no_fp64 = env_flag("MKCKKS_NO_FP64", k.no_fp64);
@@ -495,8 +495,6 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device), knobs
     MK_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));  // second client lane of reencrypt_sum
     MK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     MK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-    for (auto &ev : ev_prod_) MK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    for (auto &ev : ev_sum_) MK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     MK_HIP(hipMalloc(&d_limb_, D * sizeof(LimbConst)));
     MK_HIP(hipMemcpy(d_limb_, ps_.limb.data(), D * sizeof(LimbConst), hipMemcpyHostToDevice));
     const size_t tbytes = (size_t)D * n * sizeof(u64);
@@ -569,10 +567,6 @@ Engine::~Engine() {
     if (side_stream_) (void)hipStreamDestroy(side_stream_);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
-    for (auto ev : ev_prod_)
-        if (ev) (void)hipEventDestroy(ev);
-    for (auto ev : ev_sum_)
-        if (ev) (void)hipEventDestroy(ev);
 }
 
 Lanes Engine::lanes() const { return Lanes{stream_}; }
@@ -1445,39 +1439,23 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
     for (uint32_t i = nl; i < ext; ++i) p_mask |= 1ull << i;
     const uint32_t n_intq = (uint32_t)__builtin_popcountll(intq_mask);
     const uint32_t group = std::min(n_clients, knobs_.qsum_group);
-    const uint32_t n_groups = (n_clients + group - 1) / group;
-    // Two streams: the multiply-bound phases of client group g+1 (ModUp, P-limb inner product, ModDown conversion) run on
-    // the caller's stream while the memory-bound sums of group g (k_row_tail_sum2 on q_0, k_qsum_fp) run on the side
-    // stream; the two workspaces alternate, an event per workspace orders producer and consumer in both directions.
-    const bool overlap = side_stream_ != nullptr && !knobs_.one_lane && n_groups > 1;
+    // One stream: running the memory-bound sums of group g on a second stream beside the multiply-bound phases of group
+    // g+1 was measured neutral to slightly negative (20.47 k against 20.59 k ct/s at groups of 4): both kinds of kernel
+    // fill the register file of a CU, so the hardware time-slices them instead of co-scheduling.
     const uint32_t max_items = group * std::min(knobs_.chunk, n_ct);
     const size_t w_coef = (size_t)max_items * nl * n, w_dig = (size_t)max_items * nparts * ext * n;
     const size_t w_pc = (size_t)max_items * 2 * K * n, w_conv = (size_t)max_items * 2 * nl * n;
     const size_t w_til = (size_t)max_items * 2 * n_intq * n;
-    const size_t w_buf = w_coef + w_dig + w_pc + w_conv + w_til;
-    u64 *ws = workspace((overlap ? 2 : 1) * w_buf);
-    hipStream_t main = stream_, sum = overlap ? side_stream_ : stream_;
-    struct Restore {  // the helpers launch on stream_; put it back on every exit path
-        hipStream_t &ref, saved;
-        ~Restore() { ref = saved; }
-    } restore{stream_, main};
-    if (overlap) {  // the side stream starts behind whatever the caller's stream has done so far
-        MK_HIP(hipEventRecord(ev_fork_, main));
-        MK_HIP(hipStreamWaitEvent(sum, ev_fork_, 0));
-    }
-    uint32_t gi = 0;  // running group counter: workspace gi & 1
+    u64 *ws = workspace(w_coef + w_dig + w_pc + w_conv + w_til);
+    hipStream_t main = stream_;
     for (uint32_t b0 = 0; b0 < n_ct; b0 += knobs_.chunk) {
         const uint32_t cnt = std::min(knobs_.chunk, n_ct - b0);
-        for (uint32_t g0 = 0; g0 < n_clients; g0 += group, ++gi) {
+        for (uint32_t g0 = 0; g0 < n_clients; g0 += group) {
             const uint32_t gc = std::min(group, n_clients - g0), items = gc * cnt;
-            const uint32_t buf = overlap ? (gi & 1) : 0;
-            u64 *coef = ws + (size_t)buf * w_buf, *dig = coef + w_coef, *pc = dig + w_dig, *conv = pc + w_pc,
-                *til = conv + w_conv;
+            u64 *coef = ws, *dig = coef + w_coef, *pc = dig + w_dig, *conv = pc + w_pc, *til = conv + w_conv;
             const u64 *ct0 = cts + ((size_t)g0 * n_ct + b0) * ct_words;  // client g0, index b0
             const u64 *c1 = ct0 + (size_t)nl * n, *evk0 = evks + (size_t)g0 * evk_words;
             const size_t ct_cstride = (size_t)n_ct * ct_words;
-            stream_ = main;
-            if (overlap && gi >= 2) MK_HIP(hipStreamWaitEvent(main, ev_sum_[buf], 0));  // group gi-2's sums are done with it
             {   // ModUp of every item's c1: column-passed converted limbs; the row passes happen in the consumers
                 struct Reset {
                     bool &flag;
@@ -1505,29 +1483,19 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
                 launch_row3_inner_int_k<2, false>(aq, tabs_, nparts, ps_.L, nullptr, K, main);
             }
             MK_HIP(hipGetLastError());
-            if (overlap) {
-                MK_HIP(hipEventRecord(ev_prod_[buf], main));
-                MK_HIP(hipStreamWaitEvent(sum, ev_prod_[buf], 0));
-            }
             if (n_intq) {  // q_0: forward row pass of the ModDown conversion + tail + sum over the group's clients
                 SumArgs sa{conv, til, ct0, out + (size_t)b0 * ct_words, pinv, pinv + nl,
                            (size_t)cnt * 2 * nl * n, (size_t)cnt * 2 * n_intq * n, ct_cstride, ct_words,
                            gc, nl, n_intq, 2 * cnt, 0, 0, g0 != 0 ? 1u : 0u};
                 sa.til_compact = 1;
-                launch_row_tail_sum<4>(sa, tabs_, true, sum, 1u);
+                launch_row_tail_sum<4>(sa, tabs_, true, main, 1u);
             }
             QSumArgs qa{dig, conv, ct0, evk0, out + (size_t)b0 * ct_words, pq, ct_cstride, ct_words, evk_words, ct_words,
                         gc, cnt, nl, ext, D, ps_.alpha, fp_mask, (uint32_t)__builtin_popcountll(fp_mask), g0 != 0 ? 1u : 0u};
-            if (knobs_.qsum_geom == 3) launch_qsum3_fp<3>(qa, tabs_, nparts, sum);
-            else if (knobs_.qsum_geom == 4) launch_qsum3_fp<4>(qa, tabs_, nparts, sum);
-            else launch_qsum_fp<4>(qa, tabs_, nparts, sum);
+            if (knobs_.qsum_geom == 2) launch_qsum_fp<4>(qa, tabs_, nparts, main);
+            else launch_qsum3_fp<3>(qa, tabs_, nparts, main);
             MK_HIP(hipGetLastError());
-            if (overlap) MK_HIP(hipEventRecord(ev_sum_[buf], sum));
         }
-    }
-    if (overlap) {  // everything the side stream did is ordered before whatever follows on the caller's stream
-        MK_HIP(hipEventRecord(ev_join_, sum));
-        MK_HIP(hipStreamWaitEvent(main, ev_join_, 0));
     }
 }
 

@@ -54,8 +54,8 @@ struct Lanes {
 // measured best; every non-default value has a parity test (tests/test_gpu_parity.py).
 struct Knobs {
     uint32_t chunk = 16;         // MKCKKS_CHUNK: ciphertexts per workspace chunk
-    uint32_t qsum_group = 8;     // MKCKKS_QSUM_GROUP: clients per pass of the merged n-client flow
-    int qsum_geom = 2;           // MKCKKS_QSUM_GEOM: 2 = two-round k_qsum_fp; 3 / 4 = three-round k_qsum3_fp at 3 / 4 waves
+    uint32_t qsum_group = 4;     // MKCKKS_QSUM_GROUP: clients per pass of the merged n-client flow (4: +1 % against 8)
+    int qsum_geom = 3;           // MKCKKS_QSUM_GEOM: 3 = three-round k_qsum3_fp (3 waves per SIMD), 2 = two-round k_qsum_fp
     bool generic_ntt = false;    // MKCKKS_GENERIC_NTT=1: LDS-stage kernels for both passes
     bool no_fp64 = false;        // MKCKKS_NO_FP64=1: integer arithmetic on every limb
     bool fuse_inner = true;      // MKCKKS_FUSE_INNER=0: separate row pass + inner product (all limbs)
@@ -159,7 +159,6 @@ private:
     std::vector<uint8_t> fp_of_;  // per limb id: 1 = fp64 kernel instance
     hipStream_t side_stream_ = nullptr;  // second client lane of reencrypt_sum
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
-    hipEvent_t ev_prod_[2] = {nullptr, nullptr}, ev_sum_[2] = {nullptr, nullptr};  // merged flow: per workspace
     bool skip_rows_ = false;  // modup_core: leave the row pass of the converted digits to the fused kernels
     uint32_t *d_rot_ = nullptr;
     void *d_ksi_ = nullptr;

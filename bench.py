@@ -39,16 +39,24 @@ def algorithmic_bytes_per_unit(N, L, K, beta, n_clients):
     return pre + agg + resc
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, log):
     """The oracle (CPU restatement, OpenMP over limbs like OpenFHE's WITH_OPENMP build) on a bounded sample of
-    the same workload: `pre` ciphertexts PRE'd, summed, one rescale*const.  kind = "port"."""
+    the same workload: `pre` ciphertexts PRE'd, summed, one rescale*const.  kind = "port".  Timed twice: with ONE
+    thread and with every core this process may use; `value` is the all-core number."""
     from oracle.oracle import OracleContext, set_threads
-    # the GPU box exposes every host core but one GPU's share is 16; the restatement parallelises over <= 2L limbs
-    threads = int(os.environ.get("OMP_NUM_THREADS", min(os.cpu_count() or 1, 16)))
-    set_threads(threads)
     t0 = time.time()
     o = OracleContext(args.log_n, args.depth, args.scaling_bits, 60, dnum=args.dnum)
-    log(f"[cpu] oracle context built in {time.time() - t0:.1f}s, threads={threads}")
+    log(f"[cpu] oracle context built in {time.time() - t0:.1f}s")
     rng = np.random.default_rng(1)
     N, L, D = o.N, o.L, o.D
 
@@ -59,22 +67,56 @@ def cpu_baseline(args, log):
         return out
 
     evk = rnd(list(range(D)) * (2 * o.beta)).reshape(o.beta, 2, D, N)
-    n_pre = args.cpu_sample
     pool = [rnd(list(range(L)) * 2).reshape(2, L, N) for _ in range(4)]
-    o.reencrypt(pool[0], evk)  # untimed warm-up (page faults, OpenMP team start)
-    cts = [pool[i % 4] for i in range(n_pre)]
-    f = o.const_factors(L - 1, 1, 1.0 / n_pre)
-    t0 = time.time()
-    acc = None
-    for ct in cts:
-        r = o.reencrypt(ct, evk)
-        acc = r if acc is None else o.eval_add(acc, r)
-    o.mult_factors(o.rescale(acc), f)
-    dt = time.time() - t0
-    # amortise the single rescale the same way the GPU step does (1 per n_clients units)
-    return {"value": n_pre / dt, "unit": "ciphertexts/s", "cores": threads, "kind": "port",
-            "sample": f"{n_pre} ciphertexts PRE'd + summed + 1 rescale*const at N=2^{args.log_n}, L={L}, "
-                      f"dnum={args.dnum}; oracle/liboracle.so (OpenMP over limbs), {dt:.1f}s"}
+
+    def run(threads, n_pre):
+        set_threads(threads)
+        o.reencrypt(pool[0], evk)  # untimed warm-up (page faults, OpenMP team start)
+        cts = [pool[i % 4] for i in range(n_pre)]
+        f = o.const_factors(L - 1, 1, 1.0 / n_pre)
+        t0 = time.time()
+        acc = None
+        for ct in cts:
+            r = o.reencrypt(ct, evk)
+            acc = r if acc is None else o.eval_add(acc, r)
+        o.mult_factors(o.rescale(acc), f)  # the single rescale, amortised like the GPU step's (1 per n_clients units)
+        return n_pre / (time.time() - t0), time.time() - t0
+
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    n_all = int(os.environ.get("OMP_NUM_THREADS", avail))
+    v1, dt1 = run(1, max(2, args.cpu_sample // 48))
+    log(f"[cpu] 1 thread: {v1:.2f} ct/s ({dt1:.1f}s)")
+    va, dta = run(n_all, args.cpu_sample)
+    log(f"[cpu] {n_all} threads: {va:.2f} ct/s ({dta:.1f}s)")
+    return {"value": va, "unit": "ciphertexts/s", "cores": n_all, "kind": "port", "cpu_model": cpu_model(),
+            "threads_1": {"value": v1, "cores": 1, "sample_ciphertexts": max(2, args.cpu_sample // 48), "seconds": dt1},
+            "threads_all": {"value": va, "cores": n_all, "sample_ciphertexts": args.cpu_sample, "seconds": dta},
+            "sample": f"{args.cpu_sample} ciphertexts PRE'd + summed + 1 rescale*const at N=2^{args.log_n}, L={L}, "
+                      f"dnum={args.dnum}; oracle/liboracle.so (OpenMP over <= 2L limbs), all-core leg {dta:.1f}s, "
+                      f"1-thread leg {dt1:.1f}s on {max(2, args.cpu_sample // 48)} ciphertexts"}
+
+
+def valu_ceiling(N, log_n, L, K, beta, alpha, n_clients, fp_limbs_q):
+    """Secondary ceiling: the path is 64-bit modular arithmetic on a chip without a 64-bit
+    multiplier.  Work per unit x measured cycles per wave-operation (profiles/r01_ubench_intmul.txt, r01_ubench_fpmod.txt:
+    fp64 butterfly 61, Shoup butterfly 90, v_mad_u64_u32 5.3, v_fma_f64 4.4 cycles) against 1024 SIMDs x 2.4 GHz."""
+    D = L + K
+    bf = N // 2 * log_n                                   # butterflies of one limb transform
+    int_q = L - fp_limbs_q                                # integer-class Q limbs (60-bit q_0)
+    # limb transforms of one PRE by arithmetic class: INTT c1, ModUp targets, INTT of the P limbs, ModDown targets
+    t_int = int_q + (beta * K + (beta - 1) * int_q) + 2 * K + 2 * int_q
+    t_fp = fp_limbs_q + (beta - 1) * fp_limbs_q + 2 * fp_limbs_q
+    resc_int, resc_fp = (2 * int_q) / n_clients, (2 + 2 * (fp_limbs_q - 1)) / n_clients  # rescale, amortised
+    conv_macs = (beta * alpha * (D - alpha) + 2 * K * L) * N   # ModUp + ModDown base-conversion MACs
+    inner = 2 * beta * D * N                                # eval-key mul-adds
+    cyc = ((t_int + resc_int) * bf * 90.0 + (t_fp + resc_fp) * bf * 61.0 + conv_macs * 4 * 5.3
+           + inner * (fp_limbs_q / L * 6 * 4.4 + (1 - fp_limbs_q / L) * 30.0)) / 64.0
+    return 1024 * 2.4e9 / cyc, {
+        "limb_transforms_int": t_int, "limb_transforms_fp64": t_fp, "butterflies_per_limb": bf,
+        "base_conv_macs": conv_macs, "inner_product_muladds": inner, "simd_cycles_per_unit": cyc}
 
 
 def verify_exchange(torch, dist, ctx, pipe, agg, out, ct_in, evk, C, B, Bs, L, world, rank, inv_n, log):
@@ -123,6 +165,10 @@ def main():
     ap.add_argument("--mode", choices=["sum", "accumulate"], default="sum",
                     help="sum: one reencrypt_sum_batch call over all clients (last ModDown pass + aggregation fused); "
                          "accumulate: per-client reencrypt_accumulate_batch calls spread over --streams")
+    ap.add_argument("--shard", choices=["client", "ct"], default="client",
+                    help="N>1: client = every GPU holds its own clients, one RCCL reduce-scatter of the partial sums "
+                         "(SURVEY 8e.2); ct = every GPU holds ALL clients' re-encryption keys and a 1/N slice of the "
+                         "ciphertext indices, no collective at all (SURVEY 8e.1)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the clients' PRE batches are spread over (each with its own context/workspace)")
     args = ap.parse_args()
@@ -170,7 +216,13 @@ def main():
         side.append((st, c2))
     N, L, K, D, beta = ctx.N, ctx.L, ctx.K, ctx.D, ctx.beta
     C, B = args.clients, args.cts
-    log(f"[bench] N=2^{args.log_n} L={L} K={K} dnum={args.dnum} beta={beta}; {C} clients x {B} ct per GPU, {world} GPU(s)")
+    by_ct = world > 1 and args.shard == "ct"
+    if by_ct:  # this rank: every client of the job, B / world ciphertext indices -- the same C * B units per GPU
+        if args.mode != "sum":
+            raise SystemExit("--shard ct runs the reencrypt_sum path")
+        C, B = args.clients * world, args.cts // world
+    log(f"[bench] N=2^{args.log_n} L={L} K={K} dnum={args.dnum} beta={beta}; {C} clients x {B} ct per GPU, {world} GPU(s)"
+        + (", sharded by ciphertext index (no collective)" if by_ct else ""))
 
     # synthetic inputs, generated in HBM: residues uniform in [0, q_i), seeded per rank
     gen = torch.Generator(device=dev)
@@ -188,20 +240,49 @@ def main():
     n_lanes = 1 + len(side)
     accs = torch.empty(n_lanes, B, 2, L, N, dtype=torch.int64, device=dev)  # one running aggregate per stream
     agg = torch.empty(B, 2, L, N, dtype=torch.int64, device=dev)
-    Bs = B // world
-    shard = torch.empty(Bs, 2, L, N, dtype=torch.int64, device=dev) if world > 1 else agg
+    exchange = world > 1 and not by_ct
+    Bs = B // world if exchange else B
+    shard = torch.empty(Bs, 2, L, N, dtype=torch.int64, device=dev) if exchange else agg
     out = torch.empty(Bs, 2, L - 1, N, dtype=torch.int64, device=dev)
-    inv_n = 1.0 / (C * world)
+    inv_n = 1.0 / (C * world) if exchange else 1.0 / C
+
+    # the exchange itself: RCCL through the library's C-ABI (mkckks_reduce_scatter_sum_mod).  The communicator is
+    # bootstrapped with 128 bytes from rank 0, carried by the torch.distributed group that also provides the barriers.
+    # gloo rehearsals (every rank on one device: RCCL refuses duplicate GPUs) keep the torch.distributed collective.
+    comms = {}
+
+    def make_comm(cx):
+        if not exchange or backend != "nccl" or os.environ.get("MKCKKS_BENCH_TORCH_COLLECTIVE") == "1":
+            return None
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(cx.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            return cx.comm_create(bytes(uid.cpu().numpy().tobytes()), world, rank)
+        except Exception as e:  # keep the job alive on the torch.distributed collective
+            log(f"[bench] C-ABI communicator unavailable ({e}); using torch.distributed reduce_scatter")
+            return None
+
+    def exchange_step(cx, partial, shard_out):
+        comm = comms.get(id(cx))
+        if comm is not None:
+            cx.reduce_scatter_sum_mod(comm, partial, shard_out, Bs, L, world)
+        else:
+            reduce_partial_sums(partial, shard_out)
+            cx.reduce_mod(shard_out, Bs, L, world)
     lanes = [(None, ctx)] + side
 
     # N>1: the exchange step of batch k (reduce-scatter over xGMI, reduce_mod, rescale of this rank's shard) runs on
     # its own stream with its own context while the main stream already key-switches batch k+1; partial sums,
     # shards and outputs are double-buffered, an event per buffer keeps batch k+2 off a buffer still in flight
     pipe = None
-    if world > 1 and args.mode == "sum" and os.environ.get("MKCKKS_BENCH_SERIAL_EXCHANGE") != "1":
+    if exchange and args.mode == "sum" and os.environ.get("MKCKKS_BENCH_SERIAL_EXCHANGE") != "1":
         comm = torch.cuda.Stream(device=dev)
         cx_tail = Context(args.log_n, args.depth, args.scaling_bits, 60, dnum=args.dnum, device=local_rank)
         cx_tail.set_stream(comm.cuda_stream)
+        with torch.cuda.stream(comm):
+            comms[id(cx_tail)] = make_comm(cx_tail)
         pipe = {"comm": comm, "ctx": cx_tail, "k": 0,
                 "agg": [agg, torch.empty_like(agg)], "shard": [shard, torch.empty_like(shard)],
                 "out": [out, torch.empty_like(out)], "free": [None, None]}
@@ -216,8 +297,7 @@ def main():
         ready = main.record_event()
         with torch.cuda.stream(pipe["comm"]):
             pipe["comm"].wait_event(ready)
-            reduce_partial_sums(pipe["agg"][b], pipe["shard"][b])
-            pipe["ctx"].reduce_mod(pipe["shard"][b], Bs, L, world)
+            exchange_step(pipe["ctx"], pipe["agg"][b], pipe["shard"][b])
             pipe["ctx"].rescale_mult_const(pipe["shard"][b], pipe["out"][b], Bs, L, inv_n)
             pipe["free"][b] = pipe["comm"].record_event()
 
@@ -225,9 +305,8 @@ def main():
         if pipe is not None:
             return step_sum_pipelined()
         ctx.reencrypt_sum(ct_in, evk, agg, C, B, L)
-        if world > 1:
-            reduce_partial_sums(agg, shard)
-            ctx.reduce_mod(shard, Bs, L, world)
+        if exchange:
+            exchange_step(ctx, agg, shard)
         ctx.rescale_mult_const(shard, out, Bs, L, inv_n)
 
     def step_accumulate():
@@ -244,13 +323,14 @@ def main():
         for st, _ in side:
             main.wait_stream(st)
         ctx.eval_sum(accs, agg, n_lanes, B, L)
-        if world > 1:
+        if exchange:
             # per-GPU partial sums are canonical (< 2^61): an integer sum over <= 8 ranks cannot wrap 2^64
-            reduce_partial_sums(agg, shard)
-            ctx.reduce_mod(shard, Bs, L, world)
+            exchange_step(ctx, agg, shard)
         ctx.rescale_mult_const(shard, out, Bs, L, inv_n)
 
     step = step_sum if args.mode == "sum" else step_accumulate
+    if exchange and pipe is None:
+        comms[id(ctx)] = make_comm(ctx)
 
     def fence():
         torch.cuda.synchronize()
@@ -277,41 +357,62 @@ def main():
 
     if world > 1:
         gpu_ms = dt * 1e3  # the exchange runs on a second stream: the main-stream events miss it, wall time does not
-        if args.verify:
+        if args.verify and exchange:
             verify_exchange(torch, dist, ctx, pipe, agg, out, ct_in, evk, C, B, Bs, L, world, rank, inv_n, log)
 
     units_per_step = C * B * world
     value = units_per_step * args.steps / dt
-    bytes_unit = algorithmic_bytes_per_unit(N, L, K, beta, C * world)
+    n_summed = C * world if exchange else C            # clients folded into one aggregate
+    bytes_unit = algorithmic_bytes_per_unit(N, L, K, beta, n_summed)
     # one "launch" of the hot path = one step on one GPU (all of its kernels, serialised on one stream)
     step_s_gpu = gpu_ms / 1e3 / args.steps
     achieved = bytes_unit * C * B / step_s_gpu / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(prof) and world == 1:  # the PMC passes were taken on the single-GPU step
         try:
             rec = json.load(open(prof))
             key = f"logn{args.log_n}_L{L}_dnum{args.dnum}_C{C}_B{B}"
-            traffic = rec.get(key, {}).get("hbm_bytes_per_step")
+            if key in rec:
+                traffic = rec[key].get("hbm_bytes_per_step")
+                traffic_source = (f"profiles/hbm_traffic.json[{key}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a "
+                                  f"builder run ({rec[key].get('profile', 'see profiles/')}), NOT measured in this run")
         except Exception:
             traffic = None
+    fp_q = sum(1 for i in range(L) if int(ctx.moduli[i]) < (5 << 48))  # limbs on the fp64 kernel instances
+    ceil_ct_s, ceil_terms = valu_ceiling(N, args.log_n, L, K, beta, ctx.alpha, n_summed, fp_q)
+    per_gpu = C * B / step_s_gpu
 
+    shard_txt = ("" if world == 1 else
+                 (f"sharded by ciphertext index x{world}, no collective -> " if by_ct else
+                  "RCCL reduce_scatter(u64 sum)+reduce_mod via mkckks_reduce_scatter_sum_mod"
+                  + (" (overlapped with the next batch's key switch)" if pipe else "") + " -> "))
     result = {
-        "metric": "ciphertexts/sec aggregated+PRE at N=2^16, L=12 RNS limbs",
+        "metric": f"ciphertexts/sec aggregated+PRE at N=2^{args.log_n}, L={L} RNS limbs",
         "value": value, "unit": "ciphertexts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"C3+C4: {C} clients x {B} ct per GPU, N=2^{args.log_n}, L={L}, K={K}, dnum={args.dnum}: "
-                               + ("reencrypt_sum_batch (hybrid key-switch PRE of every client, last ModDown pass fused with the sum) -> " if args.mode == "sum" else "reencrypt_accumulate_batch (hybrid key-switch PRE folded into the aggregate) -> ")
-                               + ("RCCL reduce_scatter(u64 sum)+reduce_mod" + (" (overlapped with the next batch's key switch)" if pipe else "") + " -> " if world > 1 else "")
-                               + "rescale_mult_const(1/n)",
+                               + ("reencrypt_sum_batch (hybrid key-switch PRE of every client; row passes, inner product, "
+                                  "ModDown tail and the sum over clients fused) -> " if args.mode == "sum" else
+                                  "reencrypt_accumulate_batch (hybrid key-switch PRE folded into the aggregate) -> ")
+                               + shard_txt + "rescale_mult_const(1/n)",
                    "ring_dim": N, "limbs": L, "special_limbs": K, "dnum": args.dnum, "clients_per_gpu": C,
-                   "ct_per_client": B, "units_per_step": units_per_step, "sharding": f"clients x{world}"},
+                   "ct_per_client": B, "units_per_step": units_per_step,
+                   "sharding": (f"ciphertext index x{world}" if by_ct else f"clients x{world}")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_unit": bytes_unit, "units_per_launch": C * B,
                      "launch": "one hot-path step on one GPU (all kernels of the path)",
-                     "launch_ms": step_s_gpu * 1e3, "frac_of_measured_copy_peak": achieved / HBM_MEASURED_GBS},
+                     "launch_ms": step_s_gpu * 1e3, "frac_of_measured_copy_peak": achieved / HBM_MEASURED_GBS,
+                     "secondary": {"bound": "valu_int32_mul", "ceiling_ct_s": ceil_ct_s, "achieved_ct_s": per_gpu,
+                                   "frac": per_gpu / ceil_ct_s, "terms": ceil_terms,
+                                   "derivation": "gfx950 has no 64-bit multiplier: per unit, limb transforms x N/2 log2 N "
+                                                 "butterflies x measured cycles per wave-operation (fp64-FMA butterfly 61, "
+                                                 "Shoup butterfly on v_mad_u64_u32 90), base-conversion MACs x 4 "
+                                                 "v_mad_u64_u32 x 5.3, eval-key mul-adds x (6 v_fma_f64 x 4.4 | 30), / 64 "
+                                                 "lanes, against 1024 SIMDs x 2.4 GHz; cycle figures: "
+                                                 "profiles/r01_ubench_intmul.txt, profiles/r01_ubench_fpmod.txt"}},
     }
     if rank == 0 and world == 1 and not args.no_cpu:
         try:

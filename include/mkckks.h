@@ -165,7 +165,7 @@ int mkckks_encrypt_batch(mkckks_ctx *c, const uint64_t *d_pk, const uint64_t *d_
                          const int32_t *d_e0, const int32_t *d_e1, uint64_t *d_ct, uint32_t n_ct, uint32_t nl);
 /* scaled real coefficient vectors -> residues in EVALUATION format over nl limbs
  * (the integer half of CKKSPackedEncoding::Encode; the fp64 canonical embedding
- * is host code in ppqsflhe_amd/host/codec.hpp).  Each double (|x| < 2^120) is
+ * runs on the GPU too: mkckks_encode_batch).  Each double (|x| < 2^120) is
  * rounded to the nearest integer (ties away from zero) and that integer is
  * reduced exactly per limb: coef double[n][N] -> u64[n][nl][N]. */
 int mkckks_lift_ntt_batch(mkckks_ctx *c, const double *d_coef, uint64_t *d_out, uint32_t n, uint32_t nl);
@@ -184,7 +184,7 @@ int mkckks_decode_batch(mkckks_ctx *c, const uint64_t *d_m, double *d_vals, uint
 
 /* ---- cc->Decrypt(sk, ct, &pt)  (client/src/decryptModelWeights.cpp:81,90,108)
  * DecryptCore: m = INTT(c0 + c1*s); d_m out u64[n_ct][nl][N] (COEFFICIENT).
- * CRT interpolation + Decode run on the host (codec.hpp). */
+ * CRT interpolation + Decode follow on the GPU: mkckks_decode_batch. */
 int mkckks_decrypt_batch(mkckks_ctx *c, const uint64_t *d_ct, const uint64_t *d_sk, uint64_t *d_m,
                          uint32_t n_ct, uint32_t nl);
 
@@ -192,6 +192,27 @@ int mkckks_decrypt_batch(mkckks_ctx *c, const uint64_t *d_ct, const uint64_t *d_
  * after an RCCL ncclSum over uint64 of `n_terms` canonical residues per word,
  * reduce every word mod its limb modulus: d_ct u64[n_ct][2][nl][N] in place. */
 int mkckks_reduce_mod_batch(mkckks_ctx *c, uint64_t *d_ct, uint32_t n_ct, uint32_t nl, uint32_t n_terms);
+
+/* ---- RCCL exchange step behind the C-ABI (SURVEY.md 8b export list, 8e.2) ----
+ * Replaces the serial per-client loop of the reference's server (orchestration/server_fns.sh:62-80,
+ * orchestration/run.sh:37-43: one changeCipherDomain per client, then one aggregateEncryptedWeights):
+ * every GPU re-encrypts and sums ITS clients (mkckks_reencrypt_sum_batch), then
+ *   d_shard[b] = ( sum over ranks r of d_partial_r[rank * n_ct_shard + b] )  coefficient-wise mod q_i
+ * as ONE ncclReduceScatter(ncclUint64, ncclSum) over xGMI + a word-wise reduction (n_ranks <= 8 canonical residues
+ * below 2^61 cannot wrap 2^64).  d_partial: u64[n_ranks * n_ct_shard][2][nl][N] on every rank; d_shard:
+ * u64[n_ct_shard][2][nl][N].  Enqueued on the context's stream.  `comm` is an ncclComm_t (as void*): from
+ * mkckks_comm_create, or any communicator of the RCCL this process carries whose rank is bound to the context's
+ * device.  librccl.so.1 is resolved at first use (dlopen by SONAME: a process that already loaded an RCCL, e.g.
+ * PyTorch's, keeps that one); mkckks_comm_library() names the file.
+ * Communicator bootstrap: rank 0 calls mkckks_comm_unique_id, ships the MKCKKS_COMM_ID_BYTES bytes to the other
+ * ranks by any side channel, every rank calls mkckks_comm_create (collective: ncclCommInitRank). */
+#define MKCKKS_COMM_ID_BYTES 128
+int mkckks_comm_unique_id(void *h_id_out /* MKCKKS_COMM_ID_BYTES */);
+int mkckks_comm_create(mkckks_ctx *c, const void *h_id, int n_ranks, int rank, void **comm_out);
+int mkckks_comm_destroy(mkckks_ctx *c, void *comm);
+int mkckks_reduce_scatter_sum_mod(mkckks_ctx *c, void *comm, const uint64_t *d_partial, uint64_t *d_shard,
+                                  uint32_t n_ct_shard, uint32_t nl, uint32_t n_ranks);
+const char *mkckks_comm_library(void);
 
 /* ---- introspection for tests: copy a CRT table to the host ---------------- */
 int mkckks_ctx_twiddles(const mkckks_ctx *c, uint32_t limb, int inverse, uint64_t *h_out /*N*/);

@@ -75,8 +75,14 @@ SYMBOLS = {
     "mkckks_encode_batch": (_int, [_vp, _vp, _vp, _u32, _u32, _dbl]),
     "mkckks_decode_batch": (_int, [_vp, _vp, _vp, _u32, _u32, _dbl]),
     "mkckks_reduce_mod_batch": (_int, [_vp, _vp, _u32, _u32, _u32]),
+    "mkckks_comm_unique_id": (_int, [_vp]),
+    "mkckks_comm_create": (_int, [_vp, _vp, _int, _int, C.POINTER(_vp)]),
+    "mkckks_comm_destroy": (_int, [_vp, _vp]),
+    "mkckks_reduce_scatter_sum_mod": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32]),
+    "mkckks_comm_library": (C.c_char_p, []),
     "mkckks_ctx_twiddles": (_int, [_vp, _u32, _int, _u64p]),
 }
+COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -262,6 +268,31 @@ class Context:
 
     def reduce_mod(self, ct, n_ct, nl, n_terms):
         self._check(self._L.mkckks_reduce_mod_batch(self._h, _ptr(ct), n_ct, nl, n_terms))
+
+    # ---- RCCL exchange of the per-GPU partial sums (behind the C-ABI; librccl resolved by the library)
+    def comm_unique_id(self):
+        """Rank 0: the MKCKKS_COMM_ID_BYTES bootstrap bytes (ncclGetUniqueId) to hand to every other rank."""
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        self._check(self._L.mkckks_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_create(self, unique_id, n_ranks, rank):
+        """Collective: an ncclComm_t (opaque handle) for this context's device."""
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("communicator id must be MKCKKS_COMM_ID_BYTES long")
+        h = C.c_void_p()
+        self._check(self._L.mkckks_comm_create(self._h, C.c_char_p(unique_id), n_ranks, rank, C.byref(h)))
+        return h.value
+
+    def comm_destroy(self, comm):
+        self._check(self._L.mkckks_comm_destroy(self._h, comm))
+
+    def reduce_scatter_sum_mod(self, comm, partial, shard, n_ct_shard, nl, n_ranks):
+        self._check(self._L.mkckks_reduce_scatter_sum_mod(self._h, comm, _ptr(partial), _ptr(shard), n_ct_shard, nl,
+                                                          n_ranks))
+
+    def comm_library(self):
+        return self._L.mkckks_comm_library().decode()
 
     # ---- proxy re-encryption
     def reencrypt(self, ct, evk, out, n_ct, nl):

@@ -5,6 +5,7 @@
 #include <string>
 
 #include "../../include/mkckks.h"
+#include "comm.hpp"
 #include "engine.hpp"
 
 struct mkckks_ctx {
@@ -310,6 +311,41 @@ int mkckks_reduce_mod_batch(mkckks_ctx *c, uint64_t *ct, uint32_t n_ct, uint32_t
         need(c && ct, "null argument");
         c->eng->reduce_mod(ct, n_ct, nl, n_terms);
     });
+}
+
+int mkckks_comm_unique_id(void *h_id) {
+    return guarded([&] {
+        need(h_id, "null argument");
+        mk::comm_unique_id(h_id);
+    });
+}
+int mkckks_comm_create(mkckks_ctx *c, const void *h_id, int n_ranks, int rank, void **comm_out) {
+    return guarded([&] {
+        need(c && h_id && comm_out, "null argument");
+        if (!c->eng->has_device()) throw mk::NoDevice("host-only context: no communicator");
+        *comm_out = mk::comm_create(c->eng->device(), h_id, n_ranks, rank);
+    });
+}
+int mkckks_comm_destroy(mkckks_ctx *c, void *comm) {
+    return guarded([&] {
+        need(c != nullptr, "null argument");
+        mk::comm_destroy(comm);
+    });
+}
+int mkckks_reduce_scatter_sum_mod(mkckks_ctx *c, void *comm, const uint64_t *d_partial, uint64_t *d_shard,
+                                  uint32_t n_ct_shard, uint32_t nl, uint32_t n_ranks) {
+    return guarded([&] {
+        need(c && comm && d_partial && d_shard, "null argument");
+        c->eng->reduce_scatter_sum_mod(comm, d_partial, d_shard, n_ct_shard, nl, n_ranks);
+    });
+}
+const char *mkckks_comm_library(void) {
+    try {
+        return mk::comm_library_path();
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return "";
+    }
 }
 
 }  // extern "C"

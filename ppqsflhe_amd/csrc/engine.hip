@@ -13,6 +13,7 @@
 // streams 8-B (or 16-B) words with unit stride per lane; the limb (modulus) is uniform per
 // workgroup (blockIdx.y), so all per-limb constants sit in SGPRs.
 #include "engine.hpp"
+#include "comm.hpp"
 #include "ntt_radix.hpp"
 #include "qsum_kernels.hpp"
 #include "codec_kernels.hpp"
@@ -952,6 +953,16 @@ void Engine::reduce_mod(u64 *ct, uint32_t n_ct, uint32_t nl, uint32_t n_terms) {
     EwGeom g{ps_.n, nl, ps_.L};
     k_reduce<<<ew_grid(ps_.n, 2 * nl, n_ct), EW_THREADS, 0, stream_>>>(ct, g, d_limb_, 2 * nl);
     MK_HIP(hipGetLastError());
+}
+
+void Engine::reduce_scatter_sum_mod(void *comm, const u64 *partial, u64 *shard, uint32_t n_ct_shard, uint32_t nl,
+                                    uint32_t n_ranks) {
+    need_device();
+    check_nl(nl);
+    if (n_ranks < 1 || n_ranks > 8) throw std::invalid_argument("integer-sum collective supports 1..8 ranks (q < 2^61)");
+    if (!n_ct_shard) return;
+    comm_reduce_scatter_u64(comm, partial, shard, (size_t)n_ct_shard * 2 * nl * ps_.n, stream_);
+    reduce_mod(shard, n_ct_shard, nl, n_ranks);
 }
 
 void Engine::mult_const(u64 *ct, uint32_t n_ct, uint32_t nl, const std::vector<u64> &factors) {

@@ -78,6 +78,7 @@ public:
 
     const ParamSet &params() const { return ps_; }
     bool has_device() const { return device_ >= 0; }
+    int device() const { return device_; }
     void set_stream(hipStream_t s) { stream_ = s; }
     hipStream_t stream() const { return stream_; }
     void sync();
@@ -96,6 +97,10 @@ public:
     void rescale(const u64 *in, u64 *out, uint32_t n_ct, uint32_t nl, const std::vector<u64> *factors);
     void mult_const(u64 *ct, uint32_t n_ct, uint32_t nl, const std::vector<u64> &factors);
     void reduce_mod(u64 *ct, uint32_t n_ct, uint32_t nl, uint32_t n_terms);
+    // RCCL exchange of the per-GPU partial sums: shard[b] = (sum over ranks of partial_r[rank * n_ct_shard + b]) mod q,
+    // partial u64[n_ranks * n_ct_shard][2][nl][N] on every rank, shard u64[n_ct_shard][2][nl][N] (comm: ncclComm_t)
+    void reduce_scatter_sum_mod(void *comm, const u64 *partial, u64 *shard, uint32_t n_ct_shard, uint32_t nl,
+                                uint32_t n_ranks);
 
     // out[b] = sum over clients of ReEncrypt(cts[c][b], evks[c]); cts [C][n_ct][2][nl][N], evks [C][beta][2][D][N]
     void reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n_clients, uint32_t n_ct, uint32_t nl);

@@ -33,3 +33,21 @@ def test_bench_refuses_to_run_without_a_gpu():
         assert '"metric"' in r.stdout
     else:
         assert "no HIP device" in (r.stderr + r.stdout) or "MI355X" in (r.stderr + r.stdout)
+
+
+def test_secondary_ceiling_terms():
+    """The integer-issue ceiling in the bench line: its work terms are SURVEY.md 8(d)'s per-PRE figures."""
+    b = load_bench()
+    N, L, K, beta, alpha = 1 << 16, 12, 4, 3, 4
+    ceil, t = b.valu_ceiling(N, 16, L, K, beta, alpha, 8, 11)
+    assert t["butterflies_per_limb"] == 524288
+    assert t["limb_transforms_int"] + t["limb_transforms_fp64"] == 80          # 12 INTT + 36 NTT + 2 (4 INTT + 12 NTT)
+    assert t["limb_transforms_int"] == 1 + (3 * 4 + 2 * 1) + 8 + 2                # q_0 and the 60-bit P limbs
+    assert t["base_conv_macs"] == (3 * 4 * 12 + 2 * 4 * 12) * N                  # 9.4 M + 6.3 M
+    assert t["inner_product_muladds"] == 2 * 3 * 16 * N                          # 6.3 M
+    assert 30e3 < ceil < 60e3                                                    # ct/s per GPU
+
+
+def test_cpu_model_string():
+    b = load_bench()
+    assert isinstance(b.cpu_model(), str) and b.cpu_model()

@@ -706,3 +706,76 @@ def test_full_size_batch_properties(ctxs):
     assert torch.equal(raw, ref)
     torch.cuda.synchronize()
     g.set_stream(None)
+
+
+def test_rccl_reduce_scatter_through_the_cabi(ctxs):
+    """mkckks_reduce_scatter_sum_mod on a ONE-rank communicator: librccl loads beside the library (the copy the process
+    already carries, when torch is in it), ncclCommInitRank / ncclReduceScatter(ncclUint64, ncclSum) execute on the
+    device, and the word-wise reduction follows on the same stream.  With one rank the exchange is the identity, so the
+    result must equal reduce_mod of the input: here the input is the unreduced sum of 5 canonical terms, i.e. what 5
+    ranks' partial sums would add up to."""
+    g, _ = ctxs("ref")
+    rng = np.random.default_rng(31)
+    B, nl, terms = 3, g.L, 5
+    cts = np.stack([rand_ct(rng, g, nl, B) for _ in range(terms)])
+    raw = cts.sum(axis=0, dtype=np.uint64)
+    d_raw, d_want, d_got = g.to_device(raw), g.to_device(raw), g.empty((B, 2, nl, g.N))
+    g.reduce_mod(d_want, B, nl, terms)
+    uid = g.comm_unique_id()
+    comm = g.comm_create(uid, 1, 0)
+    try:
+        assert "rccl" in g.comm_library()
+        g.reduce_scatter_sum_mod(comm, d_raw, d_got, B, nl, terms)
+        assert np.array_equal(d_got.to_host(), d_want.to_host())
+        # in place on the rank's own block (recv == send + rank * count), as bench.py uses it
+        g.reduce_scatter_sum_mod(comm, d_raw, d_raw, B, nl, terms)
+        assert np.array_equal(d_raw.to_host(), d_want.to_host())
+    finally:
+        g.comm_destroy(comm)
+    from ppqsflhe_amd import MkckksError
+    with pytest.raises(MkckksError):
+        g.reduce_scatter_sum_mod(None, d_raw, d_got, B, nl, 2)  # no communicator
+
+
+def _run_bench(extra_args, env_extra, world):
+    """bench.py as a FRESH child process group: world ranks on device 0, collective carried by gloo (RCCL refuses two
+    ranks on one GPU), rendezvous on 127.0.0.1."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MKCKKS_BENCH_BACKEND="gloo", MKCKKS_BENCH_ONE_DEVICE="1", **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--no-cpu", "--clients", "2", "--cts", "4"] + extra_args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r
+
+
+@pytest.mark.parametrize("serial", [False, True])
+def test_bench_two_ranks_exchange_verifies(serial):
+    """bench.py's N>1 code path (BASELINE configs[3] at two ranks): per-rank reencrypt_sum, integer reduce-scatter of the
+    partial sums, reduce_mod, rescale of the rank's shard -- pipelined with the next batch (default) and serial --
+    checked by --verify against the modular sum of the all-gathered per-rank aggregates, bit for bit."""
+    import json
+    r = _run_bench(["--verify"], {"MKCKKS_BENCH_SERIAL_EXCHANGE": "1"} if serial else {}, 2)
+    assert "--verify ok" in r.stderr, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["sharding"] == "clients x2"
+    assert line["config"]["units_per_step"] == 2 * 2 * 4
+
+
+def test_bench_two_ranks_sharded_by_ciphertext_index():
+    """every rank holds all clients' keys and half of the ciphertext indices; no collective in the data path."""
+    import json
+    r = _run_bench(["--shard", "ct"], {}, 2)
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["sharding"] == "ciphertext index x2"
+    assert line["config"]["units_per_step"] == 2 * 2 * 4 and line["config"]["clients_per_gpu"] == 4
+    assert "no collective" in line["config"]["workload"]

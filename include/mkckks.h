@@ -137,18 +137,26 @@ int mkckks_moddown_batch(mkckks_ctx *c, const uint64_t *d_in, uint64_t *d_out, u
 
 /* ---- randomness for KeyGen / ReKeyGen / Encrypt, generated in HBM ------------
  * OpenFHE's TernaryUniformGenerator, DiscreteGaussianGenerator (sigma 3.19) and
- * DiscreteUniformGenerator.  Counter-based Philox4x32-10: element i of `stream_id`
- * under `seed` is a pure function of (seed, stream_id, i).  Distributional parity only
- * (OpenFHE's PRNG stream cannot be reproduced).  d_out: int8[count] / int32[count] /
+ * DiscreteUniformGenerator.  Generator: the ChaCha20 block function (RFC 8439) under a
+ * 256-bit key (h_key32: 32 HOST bytes, drawn from the OS by the callers -- getrandom(2) in
+ * ppqsflhe_amd/host/sampler.hpp): a cryptographic PRF, like OpenFHE's Blake2-based PRNG and
+ * unlike a 64-bit-seeded statistical generator.  Counter based: element i of `stream_id`
+ * is a pure function of (key, stream_id, i).  Distributional parity only (OpenFHE's PRNG
+ * stream cannot be reproduced).  d_out: int8[count] / int32[count] /
  * u64[n_polys][nl(+K)][N] (uniform in [0, q_limb), exact by rejection). */
-int mkckks_sample_ternary(mkckks_ctx *c, int8_t *d_out, size_t count, uint64_t seed, uint32_t stream_id);
-int mkckks_sample_gauss(mkckks_ctx *c, int32_t *d_out, size_t count, double sigma, uint64_t seed, uint32_t stream_id);
-int mkckks_sample_uniform(mkckks_ctx *c, uint64_t *d_out, uint32_t n_polys, uint32_t nl, int with_p, uint64_t seed,
-                          uint32_t stream_id);
+#define MKCKKS_SAMPLER_KEY_BYTES 32
+int mkckks_sample_ternary(mkckks_ctx *c, int8_t *d_out, size_t count, const uint8_t *h_key32, uint32_t stream_id);
+int mkckks_sample_gauss(mkckks_ctx *c, int32_t *d_out, size_t count, double sigma, const uint8_t *h_key32,
+                        uint32_t stream_id);
+int mkckks_sample_uniform(mkckks_ctx *c, uint64_t *d_out, uint32_t n_polys, uint32_t nl, int with_p,
+                          const uint8_t *h_key32, uint32_t stream_id);
+/* known-answer hook: the 16 output words of one ChaCha20 block (RFC 8439 2.3.2) -> d_out16 (device) */
+int mkckks_chacha20_block(mkckks_ctx *c, uint32_t *d_out16, const uint8_t *h_key32, uint32_t counter,
+                          const uint32_t *h_nonce3);
 
 /* ---- cc->KeyGen()  (client/src/keyGen.cpp:33) -----------------------------
- * randomness is supplied by the caller (host samplers in ppqsflhe_amd/host, or
- * a test's seeded vectors): s ternary int8[N], e int32[N] (COEFFICIENT),
+ * randomness is supplied by the caller (mkckks_sample_* under OS-drawn keys in
+ * ppqsflhe_amd/host, or a test's seeded vectors): s ternary int8[N], e int32[N] (COEFFICIENT),
  * a u64[D][N] uniform residues (taken as EVALUATION).
  * d_pk out u64[2][D][N], d_sk out u64[D][N] (EVALUATION). */
 int mkckks_keygen(mkckks_ctx *c, const int8_t *d_s, const uint64_t *d_a, const int32_t *d_e,

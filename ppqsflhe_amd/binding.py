@@ -69,9 +69,10 @@ SYMBOLS = {
     "mkckks_encrypt_batch": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32]),
     "mkckks_lift_ntt_batch": (_int, [_vp, _vp, _vp, _u32, _u32]),
     "mkckks_decrypt_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32]),
-    "mkckks_sample_ternary": (_int, [_vp, _vp, _sz, C.c_uint64, _u32]),
-    "mkckks_sample_gauss": (_int, [_vp, _vp, _sz, _dbl, C.c_uint64, _u32]),
-    "mkckks_sample_uniform": (_int, [_vp, _vp, _u32, _u32, _int, C.c_uint64, _u32]),
+    "mkckks_sample_ternary": (_int, [_vp, _vp, _sz, C.c_char_p, _u32]),
+    "mkckks_sample_gauss": (_int, [_vp, _vp, _sz, _dbl, C.c_char_p, _u32]),
+    "mkckks_sample_uniform": (_int, [_vp, _vp, _u32, _u32, _int, C.c_char_p, _u32]),
+    "mkckks_chacha20_block": (_int, [_vp, _vp, C.c_char_p, _u32, C.POINTER(_u32)]),
     "mkckks_encode_batch": (_int, [_vp, _vp, _vp, _u32, _u32, _dbl]),
     "mkckks_decode_batch": (_int, [_vp, _vp, _vp, _u32, _u32, _dbl]),
     "mkckks_reduce_mod_batch": (_int, [_vp, _vp, _u32, _u32, _u32]),
@@ -113,6 +114,15 @@ def load_library():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def sampler_key(key):
+    if isinstance(key, int):
+        key = int(key).to_bytes(32, "little")
+    key = bytes(key)
+    if len(key) != 32:
+        raise ValueError("sampler key must be 32 bytes")
+    return key
 
 
 def _ptr(x):
@@ -324,14 +334,22 @@ class Context:
     def lift_ntt(self, coef, out, n, nl):
         self._check(self._L.mkckks_lift_ntt_batch(self._h, _ptr(coef), _ptr(out), n, nl))
 
-    def sample_ternary(self, out, count, seed, stream_id=0):
-        self._check(self._L.mkckks_sample_ternary(self._h, _ptr(out), count, seed, stream_id))
+    # ---- samplers: `key` is the 32-byte ChaCha20 key (bytes); an int is accepted for tests and expanded
+    # little-endian with zero padding (a test vector, NOT a way to key production randomness)
+    def sample_ternary(self, out, count, key, stream_id=0):
+        self._check(self._L.mkckks_sample_ternary(self._h, _ptr(out), count, sampler_key(key), stream_id))
 
-    def sample_gauss(self, out, count, sigma, seed, stream_id=0):
-        self._check(self._L.mkckks_sample_gauss(self._h, _ptr(out), count, float(sigma), seed, stream_id))
+    def sample_gauss(self, out, count, sigma, key, stream_id=0):
+        self._check(self._L.mkckks_sample_gauss(self._h, _ptr(out), count, float(sigma), sampler_key(key), stream_id))
 
-    def sample_uniform(self, out, n_polys, nl, with_p, seed, stream_id=0):
-        self._check(self._L.mkckks_sample_uniform(self._h, _ptr(out), n_polys, nl, int(with_p), seed, stream_id))
+    def sample_uniform(self, out, n_polys, nl, with_p, key, stream_id=0):
+        self._check(self._L.mkckks_sample_uniform(self._h, _ptr(out), n_polys, nl, int(with_p), sampler_key(key), stream_id))
+
+    def chacha20_block(self, key, counter, nonce):
+        out = self.empty((16,), np.uint32)
+        n3 = (C.c_uint32 * 3)(*nonce)
+        self._check(self._L.mkckks_chacha20_block(self._h, out.ptr, sampler_key(key), counter, n3))
+        return out.to_host()
 
     def encode(self, vals, pt, n, nl, scale):
         self._check(self._L.mkckks_encode_batch(self._h, _ptr(vals), _ptr(pt), n, nl, float(scale)))

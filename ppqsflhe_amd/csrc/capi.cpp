@@ -266,23 +266,31 @@ int mkckks_lift_ntt_batch(mkckks_ctx *c, const double *coef, uint64_t *out, uint
         c->eng->lift_ntt(coef, out, n, nl);
     });
 }
-int mkckks_sample_ternary(mkckks_ctx *c, int8_t *out, size_t count, uint64_t seed, uint32_t stream_id) {
+int mkckks_sample_ternary(mkckks_ctx *c, int8_t *out, size_t count, const uint8_t *h_key32, uint32_t stream_id) {
     return guarded([&] {
-        need(c && out, "null argument");
-        c->eng->sample_ternary(out, count, seed, stream_id);
+        need(c && out && h_key32, "null argument");
+        c->eng->sample_ternary(out, count, h_key32, stream_id);
     });
 }
-int mkckks_sample_gauss(mkckks_ctx *c, int32_t *out, size_t count, double sigma, uint64_t seed, uint32_t stream_id) {
+int mkckks_sample_gauss(mkckks_ctx *c, int32_t *out, size_t count, double sigma, const uint8_t *h_key32,
+                        uint32_t stream_id) {
     return guarded([&] {
-        need(c && out, "null argument");
-        c->eng->sample_gauss(out, count, sigma, seed, stream_id);
+        need(c && out && h_key32, "null argument");
+        c->eng->sample_gauss(out, count, sigma, h_key32, stream_id);
     });
 }
-int mkckks_sample_uniform(mkckks_ctx *c, uint64_t *out, uint32_t n_polys, uint32_t nl, int with_p, uint64_t seed,
+int mkckks_sample_uniform(mkckks_ctx *c, uint64_t *out, uint32_t n_polys, uint32_t nl, int with_p, const uint8_t *h_key32,
                           uint32_t stream_id) {
     return guarded([&] {
-        need(c && out, "null argument");
-        c->eng->sample_uniform(out, n_polys, nl, with_p != 0, seed, stream_id);
+        need(c && out && h_key32, "null argument");
+        c->eng->sample_uniform(out, n_polys, nl, with_p != 0, h_key32, stream_id);
+    });
+}
+int mkckks_chacha20_block(mkckks_ctx *c, uint32_t *d_out16, const uint8_t *h_key32, uint32_t counter,
+                          const uint32_t *h_nonce3) {
+    return guarded([&] {
+        need(c && d_out16 && h_key32 && h_nonce3, "null argument");
+        c->eng->chacha_block(d_out16, h_key32, counter, h_nonce3);
     });
 }
 int mkckks_encode_batch(mkckks_ctx *c, const double *vals, uint64_t *pt, uint32_t n, uint32_t nl, double scale) {

@@ -1697,15 +1697,32 @@ void Engine::decrypt(const u64 *ct, const u64 *sk, u64 *m, uint32_t n_ct, uint32
 
 // ---- randomness ------------------------------------------------------------------------------------
 
-void Engine::sample_ternary(int8_t *out, size_t count, uint64_t seed, uint32_t sid) {
+static ChaChaKey load_key(const uint8_t *key32) {
+    if (!key32) throw std::invalid_argument("null sampler key");
+    ChaChaKey k;
+    for (int i = 0; i < 8; ++i)  // little-endian words, RFC 8439
+        k.k[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) | ((uint32_t)key32[4 * i + 2] << 16) |
+                 ((uint32_t)key32[4 * i + 3] << 24);
+    return k;
+}
+
+void Engine::chacha_block(uint32_t *d_out16, const uint8_t *key32, uint32_t counter, const uint32_t nonce[3]) {
     need_device();
-    if (!count) return;
-    k_sample_ternary<<<(unsigned)((count + 255) / 256), 256, 0, stream_>>>(out, count, seed, sid);
+    k_chacha_block<<<1, 64, 0, stream_>>>(d_out16, load_key(key32), counter, nonce[0], nonce[1], nonce[2]);
     MK_HIP(hipGetLastError());
 }
 
-void Engine::sample_gauss(int32_t *out, size_t count, double sigma, uint64_t seed, uint32_t sid) {
+void Engine::sample_ternary(int8_t *out, size_t count, const uint8_t *key32, uint32_t sid) {
     need_device();
+    const ChaChaKey key = load_key(key32);
+    if (!count) return;
+    k_sample_ternary<<<(unsigned)((count + 255) / 256), 256, 0, stream_>>>(out, count, key, sid);
+    MK_HIP(hipGetLastError());
+}
+
+void Engine::sample_gauss(int32_t *out, size_t count, double sigma, const uint8_t *key32, uint32_t sid) {
+    need_device();
+    const ChaChaKey key = load_key(key32);
     if (!count) return;
     if (!(sigma > 0) || 12.0 * sigma > GAUSS_TABLE - 1) throw std::invalid_argument("sigma out of range");
     GaussTable t{};
@@ -1723,16 +1740,17 @@ void Engine::sample_gauss(int32_t *out, size_t count, double sigma, uint64_t see
         t.thr[k] = scaled >= 18446744073709551615.0L ? ~0ull : (u64)scaled;
     }
     t.thr[t.count - 1] = ~0ull;
-    k_sample_gauss<<<(unsigned)((count + 255) / 256), 256, 0, stream_>>>(out, count, seed, sid, t);
+    k_sample_gauss<<<(unsigned)((count + 255) / 256), 256, 0, stream_>>>(out, count, key, sid, t);
     MK_HIP(hipGetLastError());
 }
 
-void Engine::sample_uniform(u64 *out, uint32_t items, uint32_t nl, bool with_p, uint64_t seed, uint32_t sid) {
+void Engine::sample_uniform(u64 *out, uint32_t items, uint32_t nl, bool with_p, const uint8_t *key32, uint32_t sid) {
     need_device();
+    const ChaChaKey key = load_key(key32);
     if (nl > ps_.L || (nl == 0 && !with_p)) throw std::invalid_argument("nl out of range");
     if (!items) return;
     const uint32_t slots = nl + (with_p ? ps_.K : 0);
-    k_sample_uniform<<<dim3((ps_.n + 255) / 256, slots, items), 256, 0, stream_>>>(out, ps_.n, nl, ps_.L, d_limb_, seed, sid);
+    k_sample_uniform<<<dim3((ps_.n + 255) / 256, slots, items), 256, 0, stream_>>>(out, ps_.n, nl, ps_.L, d_limb_, key, sid);
     MK_HIP(hipGetLastError());
 }
 

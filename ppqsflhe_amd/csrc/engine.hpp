@@ -116,10 +116,12 @@ public:
                  u64 *ct, uint32_t n_ct, uint32_t nl);
     void lift_ntt(const double *coef, u64 *out, uint32_t n, uint32_t nl);
     void decrypt(const u64 *ct, const u64 *sk, u64 *m, uint32_t n_ct, uint32_t nl);
-    // counter-based samplers (Philox4x32-10): element i of stream sid under seed, independent of launch shape
-    void sample_ternary(int8_t *out, size_t count, uint64_t seed, uint32_t sid);
-    void sample_gauss(int32_t *out, size_t count, double sigma, uint64_t seed, uint32_t sid);
-    void sample_uniform(u64 *out, uint32_t items, uint32_t nl, bool with_p, uint64_t seed, uint32_t sid);
+    // counter-based samplers (ChaCha20 block function under a 256-bit key): element i of stream sid is a pure
+    // function of (key, sid, i), independent of launch shape
+    void sample_ternary(int8_t *out, size_t count, const uint8_t *key32, uint32_t sid);
+    void sample_gauss(int32_t *out, size_t count, double sigma, const uint8_t *key32, uint32_t sid);
+    void sample_uniform(u64 *out, uint32_t items, uint32_t nl, bool with_p, const uint8_t *key32, uint32_t sid);
+    void chacha_block(uint32_t *d_out16, const uint8_t *key32, uint32_t counter, const uint32_t nonce[3]);  // KAT hook
     // CKKS canonical embedding on the device: vals [n][N/2] reals <-> plaintexts / decrypted polynomials
     void encode(const double *vals, u64 *pt, uint32_t n, uint32_t nl, double scale);
     void decode(const u64 *m, double *vals, uint32_t n, uint32_t nl, double scale);

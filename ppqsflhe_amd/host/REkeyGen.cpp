@@ -33,12 +33,12 @@ int main(int argc, char *argv[]) {
             return 1;
         }
         std::cout << "[ReKeyGen] Peer Public Key loaded from " << pk_path << std::endl;
-        const uint64_t seed = fresh_seed();
+        const SamplerKey k_u = fresh_key(), k_e0 = fresh_key(), k_e1 = fresh_key();
         int8_t *d_u = s.alloc<int8_t>((size_t)beta * N);
         int32_t *d_e0 = s.alloc<int32_t>((size_t)beta * N), *d_e1 = s.alloc<int32_t>((size_t)beta * N);
-        Session::check(mkckks_sample_ternary(s.ctx(), d_u, (size_t)beta * N, seed, 0));
-        Session::check(mkckks_sample_gauss(s.ctx(), d_e0, (size_t)beta * N, 3.19, seed, 1));
-        Session::check(mkckks_sample_gauss(s.ctx(), d_e1, (size_t)beta * N, 3.19, seed, 2));
+        Session::check(mkckks_sample_ternary(s.ctx(), d_u, (size_t)beta * N, k_u.bytes, 0));
+        Session::check(mkckks_sample_gauss(s.ctx(), d_e0, (size_t)beta * N, 3.19, k_e0.bytes, 1));
+        Session::check(mkckks_sample_gauss(s.ctx(), d_e1, (size_t)beta * N, 3.19, k_e1.bytes, 2));
         uint64_t *d_evk = s.alloc<uint64_t>((size_t)beta * 2 * D * N);
         Session::check(mkckks_rekeygen(s.ctx(), s.to_device(sk_t.data(), N), s.to_device(pk.data(), pk.size()), d_u, d_e0,
                                        d_e1, d_evk));

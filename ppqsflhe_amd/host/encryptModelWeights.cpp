@@ -77,12 +77,12 @@ int main(int argc, char *argv[]) {
         const size_t slots = s.slots();
         std::vector<double> slot_vals(n_ct * slots, 0.0);  // zero padded to N/2 slots
         for (size_t c = 0; c < n_ct; ++c) std::copy(plains[c].begin(), plains[c].end(), slot_vals.begin() + c * slots);
-        const uint64_t seed = fresh_seed();
+        const SamplerKey k_v = fresh_key(), k_e0 = fresh_key(), k_e1 = fresh_key();
         int8_t *d_v = s.alloc<int8_t>(n_ct * N);
         int32_t *d_e0 = s.alloc<int32_t>(n_ct * N), *d_e1 = s.alloc<int32_t>(n_ct * N);
-        Session::check(mkckks_sample_ternary(s.ctx(), d_v, n_ct * N, seed, 0));
-        Session::check(mkckks_sample_gauss(s.ctx(), d_e0, n_ct * N, 3.19, seed, 1));
-        Session::check(mkckks_sample_gauss(s.ctx(), d_e1, n_ct * N, 3.19, seed, 2));
+        Session::check(mkckks_sample_ternary(s.ctx(), d_v, n_ct * N, k_v.bytes, 0));
+        Session::check(mkckks_sample_gauss(s.ctx(), d_e0, n_ct * N, 3.19, k_e0.bytes, 1));
+        Session::check(mkckks_sample_gauss(s.ctx(), d_e1, n_ct * N, 3.19, k_e1.bytes, 2));
         uint64_t *d_pt = s.alloc<uint64_t>(n_ct * L * N), *d_ct = s.alloc<uint64_t>(n_ct * 2 * L * N);
         Session::check(mkckks_encode_batch(s.ctx(), s.to_device(slot_vals.data(), slot_vals.size()), d_pt, (uint32_t)n_ct, L, scale));
         Session::check(mkckks_encrypt_batch(s.ctx(), s.to_device(pk.data(), pk.size()), d_pt, d_v, d_e0, d_e1, d_ct,

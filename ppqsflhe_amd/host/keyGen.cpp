@@ -20,13 +20,14 @@ int main(int argc, char *argv[]) {
         Session s(cc);
         std::cout << "[keyGen] CryptoContext loaded from " << cc_path << std::endl;
         const uint32_t N = s.N(), D = s.D();
-        const uint64_t seed = fresh_seed();
+        // independent 256-bit OS-drawn keys for the secret, the error and the (published) uniform polynomial
+        const SamplerKey k_s = fresh_key(), k_e = fresh_key(), k_a = fresh_key();
         int8_t *d_s = s.alloc<int8_t>(N);
         int32_t *d_e = s.alloc<int32_t>(N);
         uint64_t *d_a = s.alloc<uint64_t>((size_t)D * N);
-        Session::check(mkckks_sample_ternary(s.ctx(), d_s, N, seed, 0));          // secret: uniform ternary
-        Session::check(mkckks_sample_gauss(s.ctx(), d_e, N, 3.19, seed, 1));       // error: sigma = 3.19
-        Session::check(mkckks_sample_uniform(s.ctx(), d_a, 1, s.L(), 1, seed, 2));  // a: uniform over QP
+        Session::check(mkckks_sample_ternary(s.ctx(), d_s, N, k_s.bytes, 0));          // secret: uniform ternary
+        Session::check(mkckks_sample_gauss(s.ctx(), d_e, N, 3.19, k_e.bytes, 1));       // error: sigma = 3.19
+        Session::check(mkckks_sample_uniform(s.ctx(), d_a, 1, s.L(), 1, k_a.bytes, 2));  // a: uniform over QP
         uint64_t *d_pk = s.alloc<uint64_t>((size_t)2 * D * N), *d_sk = s.alloc<uint64_t>((size_t)D * N);
         Session::check(mkckks_keygen(s.ctx(), d_s, d_a, d_e, d_pk, d_sk));
         std::vector<int8_t> sk_t(N);

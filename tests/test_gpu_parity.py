@@ -779,3 +779,47 @@ def test_bench_two_ranks_sharded_by_ciphertext_index():
     assert line["n_gpus"] == 2 and line["config"]["sharding"] == "ciphertext index x2"
     assert line["config"]["units_per_step"] == 2 * 2 * 4 and line["config"]["clients_per_gpu"] == 4
     assert "no collective" in line["config"]["workload"]
+
+
+def _chacha20_block_py(key, counter, nonce):
+    """RFC 8439 2.3 in plain Python (test-side restatement of the generator)."""
+    def rotl(v, c):
+        return ((v << c) & 0xFFFFFFFF) | (v >> (32 - c))
+
+    def qr(x, a, b, c, d):
+        x[a] = (x[a] + x[b]) & 0xFFFFFFFF; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & 0xFFFFFFFF; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & 0xFFFFFFFF; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & 0xFFFFFFFF; x[b] = rotl(x[b] ^ x[c], 7)
+
+    s = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + [int.from_bytes(key[4 * i:4 * i + 4], "little") for i in range(8)]
+    s += [counter] + list(nonce)
+    x = list(s)
+    for _ in range(10):
+        qr(x, 0, 4, 8, 12); qr(x, 1, 5, 9, 13); qr(x, 2, 6, 10, 14); qr(x, 3, 7, 11, 15)
+        qr(x, 0, 5, 10, 15); qr(x, 1, 6, 11, 12); qr(x, 2, 7, 8, 13); qr(x, 3, 4, 9, 14)
+    return [(a + b) & 0xFFFFFFFF for a, b in zip(x, s)]
+
+
+def test_sampler_generator_is_chacha20(ctxs):
+    """The device samplers run the ChaCha20 block function: RFC 8439 2.3.2 known answer, and the documented mapping
+    element i -> 64-bit word i % 8 of block i / 8 (nonce = (block >> 32, stream, attempt)) for the ternary sampler."""
+    g, _ = ctxs("tiny")
+    key = bytes(range(32))
+    got = g.chacha20_block(key, 1, (0x09000000, 0x4a000000, 0x00000000))
+    want = [0xe4e7f110, 0x15593bd1, 0x1fdd0f50, 0xc47120a3, 0xc7f4d1c7, 0x0368c033, 0x9aaa2204, 0x4e6cd4c3,
+            0x466482d2, 0x09aa9f07, 0x05d7c214, 0xa2028bd9, 0xd19c12b5, 0xb94e16de, 0xe883d0cb, 0x4e3c50a2]
+    assert [int(v) for v in got] == want
+    assert _chacha20_block_py(key, 1, (0x09000000, 0x4a000000, 0)) == want
+    n, sid = 40, 5
+    d_t = g.empty((n,), dtype=np.int8)
+    g.sample_ternary(d_t, n, key, sid)
+    t = d_t.to_host()
+    for i in range(n):
+        blk = _chacha20_block_py(key, i // 8, (0, sid, 0))
+        w = i % 8
+        r = (blk[2 * w + 1] << 32) | blk[2 * w]
+        assert int(t[i]) == ((r * 3) >> 64) - 1, i
+    from ppqsflhe_amd import MkckksError
+    with pytest.raises(ValueError):
+        g.sample_ternary(d_t, n, b"short", 0)

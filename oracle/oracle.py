@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_LIB_PATH = os.path.join(_HERE, os.environ.get("ORACLE_LIB", "liboracle.so"))  # ORACLE_LIB: the sanitizer build
 
 
 def build(force=False):

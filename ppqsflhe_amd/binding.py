@@ -92,6 +92,20 @@ def lib_path():
     return _LIB
 
 
+def hip_runtimes_loaded():
+    """Distinct libamdhip64 files mapped into this process (more than one is the "no HIP device" trap)."""
+    paths = []
+    try:
+        for line in open("/proc/self/maps"):
+            if "libamdhip64" in line:
+                p = line[line.index("/"):].strip()
+                if p not in paths:
+                    paths.append(p)
+    except (OSError, ValueError):
+        pass
+    return paths
+
+
 def load_library():
     """Load the in-tree HIP library; raise (never fall back) when it is missing."""
     global _lib
@@ -105,9 +119,14 @@ def load_library():
         # buffers (bench.py, multi-GPU), so let torch load first whenever it is installed.
         try:
             import torch  # noqa: F401
-        except Exception:
-            pass
+        except ImportError:
+            pass  # no torch in this environment: the library's own runtime is the only one
         L = C.CDLL(_LIB)
+        dup = hip_runtimes_loaded()
+        if len(dup) > 1:
+            import warnings
+            warnings.warn("two HIP runtimes in this process (" + ", ".join(dup) + "): the one initialised second sees no "
+                          "device; import torch before ppqsflhe_amd, or do not mix ROCm installations", RuntimeWarning)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)
             fn.restype = res

@@ -437,6 +437,33 @@ static dim3 ew_grid(uint32_t n, uint32_t slots, uint32_t items) {
     return dim3((n / 2 + EW_THREADS - 1) / EW_THREADS, slots, items);
 }
 
+// "no HIP device" has one non-obvious cause worth naming: two copies of the HIP runtime in one process (PyTorch-ROCm
+// ships its own libamdhip64 and loads it by path; this library links /opt/rocm's).  The copy initialised second finds no
+// device.  /proc/self/maps tells.
+static std::string hip_runtime_diagnosis() {
+    std::vector<std::string> paths;
+    if (FILE *f = std::fopen("/proc/self/maps", "r")) {
+        char line[4096];
+        while (std::fgets(line, sizeof line, f)) {
+            const char *p = std::strstr(line, "libamdhip64");
+            if (!p) continue;
+            const char *start = std::strchr(line, '/');
+            if (!start) continue;
+            std::string path(start);
+            while (!path.empty() && (path.back() == '\n' || path.back() == ' ')) path.pop_back();
+            bool seen = false;
+            for (const std::string &q : paths) seen = seen || q == path;
+            if (!seen) paths.push_back(path);
+        }
+        std::fclose(f);
+    }
+    if (paths.size() < 2) return "";
+    std::string msg = "; this process carries " + std::to_string(paths.size()) + " HIP runtimes (";
+    for (size_t i = 0; i < paths.size(); ++i) msg += (i ? ", " : "") + paths[i];
+    return msg + "): the one initialised second sees no device -- load the library that owns the device first (import torch "
+                 "before libmkckks_hip.so, or link both against the same libamdhip64)";
+}
+
 // Switches are read ONCE, when a context is created (tests and A/B runs create a context under the switch).
 static bool env_flag(const char *name, bool dflt) {
     const char *e = std::getenv(name);
@@ -473,7 +500,8 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device), knobs
     if (device_ < 0) return;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= device_)
-        throw NoDevice("no HIP device " + std::to_string(device_) + " (found " + std::to_string(count) + ")");
+        throw NoDevice("no HIP device " + std::to_string(device_) + " (found " + std::to_string(count) + ")" +
+                       hip_runtime_diagnosis());
     MK_HIP(hipSetDevice(device_));
     const uint32_t D = ps_.D, n = ps_.n;
     // N = R1 x R2 with R1 <= R2; even splits of even log N land on the radix-H kernels (16/64/256)

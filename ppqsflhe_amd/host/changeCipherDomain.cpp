@@ -40,7 +40,7 @@ int main(int argc, char *argv[]) {
         const std::vector<CtRef> refs = enumerate_cts(inputJson);
         std::vector<Ciphertext> cts;
         cts.reserve(refs.size());
-        for (const CtRef &r : refs) cts.push_back(decode_ct(ct_string(inputJson, r), N));
+        for (const CtRef &r : refs) cts.push_back(decode_ct_checked(ct_string(inputJson, r), s));
         Json outputJson = inputJson;  // layer / shape carried over; blobs replaced below
         if (!cts.empty()) {
             const uint32_t nl = cts[0].nl;

@@ -41,7 +41,7 @@ int main(int argc, char *argv[]) {
         std::vector<std::vector<double>> decoded(refs.size());
         if (!refs.empty()) {
             std::vector<Ciphertext> cts;
-            for (const CtRef &r : refs) cts.push_back(decode_ct(ct_string(encJson, r), N));
+            for (const CtRef &r : refs) cts.push_back(decode_ct_checked(ct_string(encJson, r), s));
             const uint32_t nl = cts[0].nl;
             for (const Ciphertext &c : cts)
                 if (c.nl != nl) throw std::runtime_error("ciphertexts of one file must share a level");
@@ -74,8 +74,10 @@ int main(int argc, char *argv[]) {
             Json samples = Json::array();
             std::vector<double> all;
             for (size_t k = 0; k < encLayer.at("values").size(); ++k) {
+                // encryptModelWeights packs BatchSize values per ciphertext (zero padded to N/2 slots): only those
+                // come back (decryptModelWeights.cpp:109-110: GetRealPackedValue of a batchSize-slot plaintext)
                 const std::vector<double> &v = decoded[c++];
-                all.insert(all.end(), v.begin(), v.end());
+                all.insert(all.end(), v.begin(), v.begin() + std::min<size_t>(s.batch(), v.size()));
             }
             if (all.size() > expected) all.resize(expected);  // trim the zero padding
             for (double v : all) samples.push_back(Json(v));

@@ -10,10 +10,13 @@
 // tested offline (all ciphertext/key blobs are in .MISSING_LARGE_BLOBS) -- SURVEY.md 8b "Serialization note".
 // A CC.json written by OpenFHE IS accepted: its parameters are read and the moduli re-derived and checked.
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -380,35 +383,45 @@ inline bool wants_binary_output(const std::string &out_path) {
     return out_path.size() > 5 && out_path.compare(out_path.size() - 5, 5, ".mkws") == 0;
 }
 
+struct FileCloser {
+    void operator()(FILE *f) const {
+        if (f) std::fclose(f);
+    }
+};
+using FilePtr = std::unique_ptr<FILE, FileCloser>;
+
 inline Json read_envelope(const std::string &path, bool *was_binary = nullptr) {
-    FILE *f = std::fopen(path.c_str(), "rb");
-    if (!f) throw std::runtime_error("cannot open " + path);
+    FilePtr fp(std::fopen(path.c_str(), "rb"));
+    if (!fp) throw std::runtime_error("cannot open " + path);
+    FILE *f = fp.get();
     char magic[4] = {0, 0, 0, 0};
     const bool bin = std::fread(magic, 1, 4, f) == 4 && !std::memcmp(magic, "MKWS", 4);
     if (was_binary) *was_binary = bin;
     if (!bin) {
-        std::fclose(f);
+        fp.reset();
         return Json::parse_file(path);
     }
-    auto fail = [&](const char *why) {
-        std::fclose(f);
-        throw std::runtime_error(std::string("binary envelope: ") + why);
-    };
+    auto fail = [&](const char *why) { throw std::runtime_error(std::string("binary envelope: ") + why); };
+    // every size field is checked against what the file can still hold: a hostile header cannot make us allocate
+    if (std::fseek(f, 0, SEEK_END) != 0) fail("not seekable");
+    const long long file_size = std::ftell(f);
+    if (file_size < 0 || std::fseek(f, 4, SEEK_SET) != 0) fail("not seekable");
+    auto remaining = [&]() -> uint64_t { return (uint64_t)(file_size - std::ftell(f)); };
     uint32_t version = 0;
     uint64_t skel_len = 0, n_blobs = 0;
     if (std::fread(&version, 4, 1, f) != 1 || version != 1) fail("unsupported version");
-    if (std::fread(&skel_len, 8, 1, f) != 1 || skel_len > (1ull << 32)) fail("bad skeleton size");
+    if (std::fread(&skel_len, 8, 1, f) != 1 || skel_len > remaining()) fail("bad skeleton size");
     std::string skel(skel_len, '\0');
     if (skel_len && std::fread(&skel[0], 1, skel_len, f) != skel_len) fail("truncated skeleton");
-    if (std::fread(&n_blobs, 8, 1, f) != 1 || n_blobs > (1ull << 32)) fail("bad blob count");
+    if (std::fread(&n_blobs, 8, 1, f) != 1 || n_blobs > remaining() / 8) fail("bad blob count");
     std::vector<std::string> blobs(n_blobs);
     for (std::string &b : blobs) {
         uint64_t sz = 0;
-        if (std::fread(&sz, 8, 1, f) != 1 || sz > (1ull << 36)) fail("bad blob size");
+        if (std::fread(&sz, 8, 1, f) != 1 || sz > remaining()) fail("bad blob size");
         b.resize(sz);
         if (sz && std::fread(&b[0], 1, sz, f) != sz) fail("truncated blob");
     }
-    std::fclose(f);
+    fp.reset();
     Json doc = Json::parse(skel);
     std::vector<bool> used(blobs.size(), false);
     for_each_ct_field(doc, [&](Json &field) {
@@ -454,6 +467,148 @@ inline void write_envelope(const Json &doc, const std::string &path, bool binary
         std::fwrite(b.data(), 1, b.size(), f);
     }
     if (std::fclose(f) != 0) throw std::runtime_error("cannot write " + path);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ciphertexts arrive from clients: nothing in a blob is trusted.  The kernels assume canonical residues (lazy sums of
+// <= 4 terms in k_sum, 30-bit halves below 2^30 in the conversions, values below 2^51 on the fp64 limbs) and the level
+// the header claims decides which constants a rescale uses, so a file that breaks either is refused here instead of
+// silently producing a wrong aggregate for every client.
+// ------------------------------------------------------------------------------------------------
+inline void validate_ct(const Ciphertext &ct, const Session &s) {
+    const uint32_t N = s.N(), L = s.L();
+    if (ct.nl < 1 || ct.nl > L) throw std::runtime_error("ciphertext: limb count outside [1, L]");
+    if (ct.level != L - ct.nl) throw std::runtime_error("ciphertext: level does not match its limb count");
+    if (ct.noise_deg != 1 && ct.noise_deg != 2) throw std::runtime_error("ciphertext: noiseScaleDeg must be 1 or 2");
+    if (!(ct.scale > 0) || !std::isfinite(ct.scale)) throw std::runtime_error("ciphertext: bad scaling factor");
+    if (ct.slots > N / 2) throw std::runtime_error("ciphertext: slot count exceeds N/2");
+    if (ct.data.size() != (size_t)2 * ct.nl * N) throw std::runtime_error("ciphertext: wrong payload size");
+    for (uint32_t comp = 0; comp < 2; ++comp)
+        for (uint32_t i = 0; i < ct.nl; ++i) {
+            const uint64_t q = s.moduli()[i];
+            const uint64_t *p = &ct.data[((size_t)comp * ct.nl + i) * N];
+            uint64_t bad = 0;
+            for (uint32_t k = 0; k < N; ++k) bad |= (uint64_t)(p[k] >= q);
+            if (bad) throw std::runtime_error("ciphertext: residue not below its modulus");
+        }
+}
+inline Ciphertext decode_ct_checked(const std::string &blob, const Session &s) {
+    Ciphertext ct = decode_ct(blob, s.N());
+    validate_ct(ct, s);
+    return ct;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Aggregation over n encrypted-weights files (aggregateEncryptedWeights.cpp:68-115): one output entry per tuple of
+// entries with equal "layer" and "shape" -- for two files exactly the reference's nested loops (every matching (w2, w1)
+// pair, duplicates included), for more files the same nesting continued file by file.
+// ------------------------------------------------------------------------------------------------
+struct AggItem {
+    std::vector<const std::string *> blobs;  // one per file
+    size_t out_layer;
+    int field;  // 0 mean, 1 std_dev, 2 values[idx]
+    size_t idx;
+};
+inline void match_layers(const std::vector<Json> &files, size_t f, std::vector<const Json *> &cur,
+                         std::vector<std::vector<const Json *>> &out) {
+    if (f == files.size()) {
+        out.push_back(cur);
+        return;
+    }
+    for (const Json &w : files[f].at("weights_summary").a) {
+        if (f > 0 && !(w.at("layer") == cur[0]->at("layer") && w.at("shape") == cur[0]->at("shape"))) continue;
+        cur.push_back(&w);
+        match_layers(files, f + 1, cur, out);
+        cur.pop_back();
+    }
+}
+inline std::vector<AggItem> build_agg_items(const std::vector<Json> &files, Json &outputJson) {
+    outputJson = Json::object();
+    outputJson["weights_summary"] = Json::array();
+    std::vector<std::vector<const Json *>> tuples;
+    std::vector<const Json *> cur;
+    match_layers(files, 0, cur, tuples);
+    std::vector<AggItem> items;
+    for (const auto &match : tuples) {
+        Json agg = Json::object();
+        agg["layer"] = match[0]->at("layer");
+        agg["shape"] = match[0]->at("shape");
+        size_t nvals = (size_t)-1;
+        for (const Json *m : match) nvals = std::min(nvals, m->at("values").size());
+        Json vals = Json::array();
+        for (size_t k = 0; k < nvals; ++k) vals.push_back(Json(""));
+        agg["values"] = vals;
+        const size_t out_layer = outputJson["weights_summary"].size();
+        outputJson["weights_summary"].push_back(agg);
+        AggItem mean{{}, out_layer, 0, 0}, sd{{}, out_layer, 1, 0};
+        for (const Json *m : match) {
+            mean.blobs.push_back(&m->at("mean").as_string());
+            sd.blobs.push_back(&m->at("std_dev").as_string());
+        }
+        items.push_back(mean);
+        items.push_back(sd);
+        for (size_t k = 0; k < nvals; ++k) {
+            AggItem v{{}, out_layer, 2, k};
+            for (const Json *m : match) v.blobs.push_back(&m->at("values").at(k).as_string());
+            items.push_back(v);
+        }
+    }
+    return items;
+}
+// the ciphertexts of every item, file-major: flat [file][item][2][nl][N]; all must share level and scale
+inline Ciphertext gather_agg_inputs(const std::vector<AggItem> &items, size_t n_files, const Session &s,
+                                    std::vector<uint64_t> &flat) {
+    const uint32_t N = s.N();
+    Ciphertext first = decode_ct_checked(*items[0].blobs[0], s);
+    const uint32_t nl = first.nl;
+    const size_t words = (size_t)2 * nl * N, B = items.size();
+    flat.resize(n_files * B * words);
+    for (size_t b = 0; b < B; ++b)
+        for (size_t f = 0; f < n_files; ++f) {
+            Ciphertext ct = decode_ct_checked(*items[b].blobs[f], s);
+            if (ct.nl != nl || ct.noise_deg != first.noise_deg || ct.scale != first.scale)
+                throw std::runtime_error("EvalAdd operands differ in level or scale");
+            std::memcpy(&flat[(f * B + b) * words], ct.data.data(), words * 8);
+        }
+    first.data.clear();
+    return first;
+}
+// EvalMult(sum, 1/n) (aggregateEncryptedWeights.cpp:83,92,107) on d_sum [B][2][nl][N] and the output document
+inline void finish_aggregate(Session &s, const std::vector<AggItem> &items, uint64_t *d_sum, const Ciphertext &first,
+                             size_t n_clients, Json &outputJson) {
+    const uint32_t N = s.N(), nl = first.nl;
+    const size_t B = items.size();
+    Ciphertext res;
+    uint64_t *d_out = d_sum;
+    const double operand = 1.0 / (double)n_clients;  // 0.5 for the reference's two clients
+    if (first.noise_deg == 2) {
+        // EvalMult(ct, double): rescale first (ModReduceInternalInPlace), then the integer constant
+        if (nl < 2) throw std::runtime_error("ciphertext has no limb left to rescale");
+        d_out = s.alloc<uint64_t>(B * (size_t)2 * (nl - 1) * N);
+        Session::check(mkckks_rescale_mult_const_batch(s.ctx(), d_sum, d_out, (uint32_t)B, nl, operand));
+        res.nl = nl - 1;
+        res.level = first.level + 1;
+        res.scale = first.scale / (double)s.moduli()[nl - 1] * s.sf(res.level, false);
+        res.noise_deg = 2;
+    } else {
+        Session::check(mkckks_mult_const_batch(s.ctx(), d_sum, (uint32_t)B, nl, operand));
+        res.nl = nl;
+        res.level = first.level;
+        res.scale = first.scale * s.sf(first.level, false);
+        res.noise_deg = first.noise_deg + 1;
+    }
+    res.slots = first.slots;
+    const size_t owords = (size_t)2 * res.nl * N;
+    std::vector<uint64_t> out(B * owords);
+    s.to_host(out.data(), d_out, out.size());
+    for (size_t b = 0; b < B; ++b) {
+        res.data.assign(out.begin() + b * owords, out.begin() + (b + 1) * owords);
+        Json &lay = outputJson["weights_summary"].a[items[b].out_layer];
+        std::string b64 = encode_ct(res, N);
+        if (items[b].field == 0) lay["mean"] = std::move(b64);
+        else if (items[b].field == 1) lay["std_dev"] = std::move(b64);
+        else lay["values"].a[items[b].idx] = Json(std::move(b64));
+    }
 }
 
 }  // namespace mkh

@@ -207,6 +207,15 @@ private:
     }
     struct Parser {
         const char *cur, *end;
+        int depth = 0;                          // nesting of the value being parsed
+        static constexpr int MAX_DEPTH = 64;    // OpenFHE's cereal documents nest about 12 deep; input is untrusted
+        struct Nest {
+            Parser &p;
+            explicit Nest(Parser &q) : p(q) {
+                if (++p.depth > MAX_DEPTH) p.fail("nesting too deep");
+            }
+            ~Nest() { --p.depth; }
+        };
         void ws() { while (cur < end && (*cur == ' ' || *cur == '\n' || *cur == '\t' || *cur == '\r')) ++cur; }
         [[noreturn]] void fail(const char *m) { throw std::runtime_error(std::string("json parse error: ") + m); }
         Json value() {
@@ -228,6 +237,7 @@ private:
             cur += n;
         }
         Json object() {
+            Nest nest(*this);
             Json j = Json::object();
             ++cur;
             ws();
@@ -247,6 +257,7 @@ private:
             }
         }
         Json array() {
+            Nest nest(*this);
             Json j = Json::array();
             ++cur;
             ws();

@@ -1,0 +1,104 @@
+// serverRound -- the server side of one federated round in ONE program.
+//
+// The reference's server step is a loop of processes (orchestration/server_fns.sh:62-80, orchestration/run.sh:37-43):
+//   changeCipherDomain <cc> <rekey_c> <enc_c> <tmp_c>      for every client c that is not in the target key domain
+//   aggregateEncryptedWeights <cc> <enc_target> <tmp_...> <out>
+// each of which re-loads the CryptoContext, re-parses base64-in-JSON and moves every ciphertext through the host.  Here:
+//   serverRound <cc_path> <output_aggfile> <rekey_1|-> <encfile_1> [<rekey_2|-> <encfile_2> ...]
+// "-" as the re-encryption key marks a client whose ciphertexts already are in the target domain (the reference's
+// client 2).  All ciphertexts go to HBM once; the re-encryption of every re-keyed client and the sum over clients is ONE
+// mkckks_reencrypt_sum_batch call (cc->ReEncrypt x n at changeCipherDomain.cpp:74 + the EvalAdd chain of
+// aggregateEncryptedWeights.cpp:82), then EvalMult(., 1/n) (:83).  The output file is bit-identical to the one the
+// per-client programs produce (PRE is deterministic; tests/test_cli_hosts.py).
+#include "hostlib.hpp"
+using namespace mkh;
+
+int main(int argc, char *argv[]) {
+    if (argc < 5 || (argc - 3) % 2 != 0) {
+        std::cerr << "Usage: " << argv[0] << " <cc_path> <output_aggfile> <rekey_1|-> <encfile_1> [<rekey_2|-> <encfile_2> ...]"
+                  << std::endl;
+        return 1;
+    }
+    const std::string cc_path = argv[1], output_file = argv[2];
+    std::vector<std::string> rekey_paths, enc_paths;
+    for (int i = 3; i + 1 < argc; i += 2) {
+        rekey_paths.push_back(argv[i]);
+        enc_paths.push_back(argv[i + 1]);
+    }
+    CcFile cc;
+    try {
+        cc = read_cc(cc_path);
+    } catch (const std::exception &) {
+        std::cerr << "[round] ERROR: Failed to load CryptoContext from " << cc_path << std::endl;
+        return 1;
+    }
+    try {
+        Session s(cc);
+        std::cout << "[round] CryptoContext loaded\n";
+        const uint32_t N = s.N(), D = s.D(), beta = s.beta();
+        const size_t n_clients = enc_paths.size(), evk_words = (size_t)beta * 2 * D * N;
+        // clients with a re-encryption key first (their ciphertexts feed mkckks_reencrypt_sum_batch), the others after
+        std::vector<size_t> order;
+        for (size_t c = 0; c < n_clients; ++c)
+            if (rekey_paths[c] != "-") order.push_back(c);
+        const size_t n_pre = order.size();
+        for (size_t c = 0; c < n_clients; ++c)
+            if (rekey_paths[c] == "-") order.push_back(c);
+        std::vector<uint64_t> evks(n_pre * evk_words);
+        for (size_t k = 0; k < n_pre; ++k) {
+            std::vector<uint64_t> evk;
+            if (!read_key_file(rekey_paths[order[k]], KIND_RK, N, D, 2 * beta, evk)) {
+                std::cerr << "[round] ERROR: Failed to load ReKey from " << rekey_paths[order[k]] << std::endl;
+                return 1;
+            }
+            std::memcpy(&evks[k * evk_words], evk.data(), evk_words * 8);
+        }
+        std::cout << "[round] " << n_pre << " ReKey(s) loaded\n";
+        std::vector<Json> files;
+        bool binary = false;  // the output keeps the first input's envelope form
+        for (size_t k = 0; k < n_clients; ++k) {
+            bool b = false;
+            try {
+                files.push_back(read_envelope(enc_paths[order[k]], &b));
+            } catch (const std::exception &) {
+                std::cerr << "[round] ERROR: Could not open input encrypted weights file " << enc_paths[order[k]] << std::endl;
+                return 1;
+            }
+            if (k == 0) binary = b;
+        }
+        raw_blobs() = binary;
+        Json outputJson;
+        const std::vector<AggItem> items = build_agg_items(files, outputJson);
+        if (!items.empty()) {
+            std::vector<uint64_t> flat;  // [client in `order`][ct][2][nl][N]
+            const Ciphertext first = gather_agg_inputs(items, n_clients, s, flat);
+            const uint32_t nl = first.nl;
+            const size_t B = items.size(), words = (size_t)2 * nl * N;
+            // device layout: [re-keyed clients][one slot for their re-encrypted sum][clients already in the domain]:
+            // the slot and what follows it are the terms of the final n-ary EvalAdd, no copy in between
+            const size_t n_plain = n_clients - n_pre, blk = B * words;
+            uint64_t *d_all = s.alloc<uint64_t>((n_clients + 1) * blk);
+            uint64_t *d_slot = d_all + n_pre * blk;
+            if (n_pre) Session::check(mkckks_upload(s.ctx(), d_all, flat.data(), n_pre * blk * 8));
+            if (n_plain) Session::check(mkckks_upload(s.ctx(), d_slot + blk, flat.data() + n_pre * blk, n_plain * blk * 8));
+            uint64_t *d_sum = d_slot;
+            if (n_pre) {
+                uint64_t *d_evk = s.to_device(evks.data(), evks.size());
+                Session::check(mkckks_reencrypt_sum_batch(s.ctx(), d_all, d_evk, d_slot, (uint32_t)n_pre, (uint32_t)B, nl));
+            }
+            if (n_plain) {
+                const uint64_t *d_terms = n_pre ? d_slot : d_slot + blk;
+                d_sum = s.alloc<uint64_t>(blk);
+                Session::check(mkckks_eval_sum_batch(s.ctx(), d_terms, d_sum, (uint32_t)(n_plain + (n_pre ? 1 : 0)),
+                                                     (uint32_t)B, nl));
+            }
+            finish_aggregate(s, items, d_sum, first, n_clients, outputJson);
+        }
+        write_envelope(outputJson, output_file, binary);
+    } catch (const std::exception &e) {
+        std::cerr << "[round] ERROR: " << e.what() << std::endl;
+        return 1;
+    }
+    std::cout << "[round] Re-encryption and aggregation completed successfully. Output: " << output_file << std::endl;
+    return 0;
+}

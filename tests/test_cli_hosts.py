@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "ppqsflhe_amd", "host", "build")
 PROGS = ["genCC", "keyGen", "REkeyGen", "encryptModelWeights", "changeCipherDomain", "aggregateEncryptedWeights",
-         "decryptModelWeights"]
+         "decryptModelWeights", "serverRound"]
 
 
 def run(prog, *args, env=None):
@@ -31,6 +31,7 @@ def test_binaries_exist():
     ("decryptModelWeights", "<cc_path> <privkey_path> <input_encfile> <output_file>"),
     ("keyGen", "<cc_path> <pubkey_out> <privkey_out>"),
     ("REkeyGen", "<cc.json> <client_privkey.json> <peer_pubkey.json> <rekey_out.json>"),
+    ("serverRound", "<cc_path> <output_aggfile> <rekey_1|-> <encfile_1>"),
 ])
 def test_usage_errors_exit_1(prog, usage):
     r = run(prog)
@@ -309,3 +310,164 @@ def test_garbage_private_key_exits_1_without_gpu(tmp_path, golden_dir):
     (tmp_path / "junk.key").write_text("not a key")
     r = run("decryptModelWeights", cc, tmp_path / "junk.key", tmp_path / "a", tmp_path / "b")
     assert r.returncode == 1 and "[decrypt] ERROR" in r.stderr
+
+
+def _small_cc(tmp_path, batch=None):
+    """genCC at the reference's depth/scaling; BatchSize as asked (default N/2 = 8192)."""
+    cfg = tmp_path / "config_cc.json"
+    cfg.write_text(json.dumps({"MultiplicativeDepth": 2, "ScalingModSize": 40, "BatchSize": batch or 8192,
+                               "PREMode": "INDCPA"}))
+    cc = tmp_path / "CC.json"
+    r = run("genCC", cfg, cc)
+    assert r.returncode == 0, r.stderr
+    return cc
+
+
+def _weights(tmp_path, name, layers):
+    p = tmp_path / name
+    p.write_text(json.dumps({"weights_summary": [
+        {"layer": n, "shape": [len(v)], "mean": float(np.mean(v)) if len(v) else 0.0,
+         "std_dev": float(np.std(v)) if len(v) else 0.0, "values": [float(x) for x in v]} for n, v in layers]}))
+    return p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 5])
+def test_server_round_n_clients_equals_the_per_client_programs(tmp_path, n):
+    """the n-client round.  Route A (the reference's loop, orchestration/server_fns.sh:62-80): one
+    changeCipherDomain per client 1..n-1 into client n's domain, then aggregateEncryptedWeights over the n files.
+    Route B: ONE serverRound call (mkckks_reencrypt_sum_batch + rescale_mult_const(1/n)).  PRE is deterministic, so
+    the two aggregate files must be identical byte for byte; decrypted, they are the plaintext mean within 2^-25."""
+    cc = _small_cc(tmp_path)
+    rng = np.random.default_rng(40 + n)
+
+    def ok(r):
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r
+
+    vals = [[("dense", rng.uniform(-0.3, 0.3, 700)), ("bias", rng.uniform(-0.3, 0.3, 5)), ("empty", [])] for _ in range(n)]
+    for c in range(n):
+        ok(run("keyGen", cc, tmp_path / f"pk{c}", tmp_path / f"sk{c}"))
+    for c in range(n):
+        ok(run("encryptModelWeights", cc, tmp_path / f"pk{c}", _weights(tmp_path, f"w{c}.json", vals[c]), tmp_path / f"enc{c}.json"))
+    target = n - 1
+    for c in range(n - 1):
+        ok(run("REkeyGen", cc, tmp_path / f"sk{c}", tmp_path / f"pk{target}", tmp_path / f"rk{c}"))
+        ok(run("changeCipherDomain", cc, tmp_path / f"rk{c}", tmp_path / f"enc{c}.json", tmp_path / f"pre{c}.json"))
+    # route A: target's own file first (the reference's <client2_encfile>), then the re-encrypted ones
+    ok(run("aggregateEncryptedWeights", cc, tmp_path / f"enc{target}.json", tmp_path / "pre0.json", tmp_path / "aggA.json",
+           *[tmp_path / f"pre{c}.json" for c in range(1, n - 1)]))
+    # route B: one program; "-" marks the client that already is in the target domain
+    args = []
+    for c in range(n - 1):
+        args += [tmp_path / f"rk{c}", tmp_path / f"enc{c}.json"]
+    r = ok(run("serverRound", cc, tmp_path / "aggB.json", "-", tmp_path / f"enc{target}.json", *args))
+    assert "[round] Re-encryption and aggregation completed successfully" in r.stdout
+    a, b = json.load(open(tmp_path / "aggA.json")), json.load(open(tmp_path / "aggB.json"))
+    assert [l["layer"] for l in a["weights_summary"]] == ["dense", "bias", "empty"]
+    # route B orders the re-keyed clients first: the modular sum does not depend on the order, the blobs are identical
+    assert a == b
+    ok(run("decryptModelWeights", cc, tmp_path / f"sk{target}", tmp_path / "aggB.json", tmp_path / "dec.json"))
+    dec = json.load(open(tmp_path / "dec.json"))["weights_summary"]
+    for li, (name, _) in enumerate(vals[0][:2]):
+        mean = np.mean([np.asarray(vals[c][li][1]) for c in range(n)], axis=0)
+        assert np.abs(np.array(dec[li]["values"]) - mean).max() < 2.0 ** -25, name
+    assert dec[2]["values"] == []
+    # every client re-keyed (no "-"): same sum as changeCipherDomain on all n + aggregate
+    r = run("serverRound", cc, tmp_path / "x.json", tmp_path / "rk0")  # odd argument count -> usage, exit 1
+    assert r.returncode == 1 and "Usage:" in r.stderr
+    r = run("serverRound", cc, tmp_path / "x.json", tmp_path / "nope", tmp_path / "enc0.json")
+    assert r.returncode == 1 and "[round] ERROR: Failed to load ReKey" in r.stderr
+
+
+@pytest.mark.gpu
+def test_aggregate_emits_one_entry_per_matching_pair(tmp_path):
+    """aggregateEncryptedWeights.cpp:68-72,115: the reference's nested loops emit an output entry for EVERY (w2, w1) pair
+    with equal layer and shape -- duplicate layer names included -- and none for unmatched entries."""
+    cc = _small_cc(tmp_path)
+    rng = np.random.default_rng(7)
+
+    def ok(r):
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r
+
+    a1, a2, b1 = rng.uniform(-0.3, 0.3, 6), rng.uniform(-0.3, 0.3, 6), rng.uniform(-0.3, 0.3, 6)
+    ok(run("keyGen", cc, tmp_path / "pk", tmp_path / "sk"))
+    # file 2 (the reference's client 2): layer "dup" twice, and a layer the other file lacks
+    ok(run("encryptModelWeights", cc, tmp_path / "pk", _weights(tmp_path, "w2.json", [("dup", a1), ("dup", a2), ("only2", a1)]),
+           tmp_path / "enc2.json"))
+    ok(run("encryptModelWeights", cc, tmp_path / "pk", _weights(tmp_path, "w1.json", [("dup", b1), ("other_shape", b1[:3])]),
+           tmp_path / "enc1.json"))
+    ok(run("aggregateEncryptedWeights", cc, tmp_path / "enc2.json", tmp_path / "enc1.json", tmp_path / "agg.json"))
+    ok(run("decryptModelWeights", cc, tmp_path / "sk", tmp_path / "agg.json", tmp_path / "dec.json"))
+    dec = json.load(open(tmp_path / "dec.json"))["weights_summary"]
+    assert [l["layer"] for l in dec] == ["dup", "dup"]            # one entry per matching pair, in file-2 order
+    assert np.abs(np.array(dec[0]["values"]) - (a1 + b1) / 2).max() < 2.0 ** -25
+    assert np.abs(np.array(dec[1]["values"]) - (a2 + b1) / 2).max() < 2.0 ** -25
+
+
+@pytest.mark.gpu
+def test_batch_size_below_half_ring(tmp_path):
+    """genCC accepts BatchSize < N/2 (genCC.cpp:54): encryptModelWeights then packs BatchSize values per ciphertext and
+    decryptModelWeights must return exactly those (decryptModelWeights.cpp:109-110), also for a layer that spans several
+    ciphertexts with a ragged tail."""
+    cc = _small_cc(tmp_path, batch=256)
+    rng = np.random.default_rng(9)
+    vals = rng.uniform(-0.3, 0.3, 256 * 2 + 77)  # three ciphertexts, the last one ragged
+
+    def ok(r):
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r
+
+    ok(run("keyGen", cc, tmp_path / "pk", tmp_path / "sk"))
+    r = ok(run("encryptModelWeights", cc, tmp_path / "pk", _weights(tmp_path, "w.json", [("big", vals)]), tmp_path / "enc.json"))
+    assert "Batch size from CryptoContext = 256" in r.stdout
+    assert len(json.load(open(tmp_path / "enc.json"))["weights_summary"][0]["values"]) == 3
+    ok(run("decryptModelWeights", cc, tmp_path / "sk", tmp_path / "enc.json", tmp_path / "dec.json"))
+    got = np.array(json.load(open(tmp_path / "dec.json"))["weights_summary"][0]["values"])
+    assert got.size == vals.size
+    assert np.abs(got - vals).max() < 2.0 ** -25
+
+
+@pytest.mark.gpu
+def test_malformed_client_ciphertexts_are_refused(tmp_path):
+    """A client file is untrusted input: residues at or above their modulus, a level that contradicts the limb count, or
+    a noiseScaleDeg outside {1, 2} must end in "[...] ERROR" + exit 1, never in a silently wrong aggregate."""
+    import base64
+    import struct
+    cc = _small_cc(tmp_path)
+
+    def ok(r):
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r
+
+    ok(run("keyGen", cc, tmp_path / "pk", tmp_path / "sk"))
+    ok(run("keyGen", cc, tmp_path / "pk2", tmp_path / "sk2"))
+    ok(run("REkeyGen", cc, tmp_path / "sk", tmp_path / "pk2", tmp_path / "rk"))
+    ok(run("encryptModelWeights", cc, tmp_path / "pk", _weights(tmp_path, "w.json", [("l", np.linspace(-0.2, 0.2, 9))]),
+           tmp_path / "enc.json"))
+    good = json.load(open(tmp_path / "enc.json"))
+
+    def tamper(fn, name):
+        doc = json.loads(json.dumps(good))
+        blob = bytearray(base64.b64decode(doc["weights_summary"][0]["mean"]))
+        fn(blob)
+        doc["weights_summary"][0]["mean"] = base64.b64encode(bytes(blob)).decode()
+        p = tmp_path / name
+        p.write_text(json.dumps(doc))
+        return p
+
+    def residue_too_big(b):
+        b[48:56] = struct.pack("<Q", (1 << 64) - 1)
+    def wrong_level(b):
+        b[24:28] = struct.pack("<I", 2)     # header.level, although all 4 limbs are present
+    def wrong_deg(b):
+        b[28:32] = struct.pack("<I", 7)     # header.noise_deg
+    for fn, name in ((residue_too_big, "big.json"), (wrong_level, "lvl.json"), (wrong_deg, "deg.json")):
+        bad = tamper(fn, name)
+        r = run("changeCipherDomain", cc, tmp_path / "rk", bad, tmp_path / "o.json")
+        assert r.returncode == 1 and "[recrypt] ERROR" in r.stderr, name
+        r = run("aggregateEncryptedWeights", cc, tmp_path / "enc.json", bad, tmp_path / "o.json")
+        assert r.returncode == 1 and "[agg] ERROR" in r.stderr, name
+        r = run("serverRound", cc, tmp_path / "o.json", "-", tmp_path / "enc.json", tmp_path / "rk", bad)
+        assert r.returncode == 1 and "[round] ERROR" in r.stderr, name

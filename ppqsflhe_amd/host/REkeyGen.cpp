@@ -28,7 +28,7 @@ int main(int argc, char *argv[]) {
             return 1;
         }
         std::cout << "[ReKeyGen] Client Private Key loaded from " << sk_path << std::endl;
-        if (!read_key_file(pk_path, KIND_PK, N, D, 2, pk)) {
+        if (!load_public_key(s, pk_path, pk)) {
             std::cerr << "Error loading Peer public key from " << pk_path << std::endl;
             return 1;
         }

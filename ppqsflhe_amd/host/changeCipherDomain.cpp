@@ -21,9 +21,9 @@ int main(int argc, char *argv[]) {
     try {
         Session s(cc);
         std::cout << "[recrypt] CryptoContext loaded\n";
-        const uint32_t N = s.N(), D = s.D(), beta = s.beta();
+        const uint32_t N = s.N();
         std::vector<uint64_t> evk;
-        if (!read_key_file(rekey_path, KIND_RK, N, D, 2 * beta, evk)) {
+        if (!load_eval_key(s, rekey_path, evk)) {
             std::cerr << "[recrypt] ERROR: Failed to load ReKey from " << rekey_path << std::endl;
             return 1;
         }

@@ -23,11 +23,11 @@ int main(int argc, char *argv[]) {
     try {
         Session s(cc);
         std::cout << "[encrypt] CryptoContext loaded from " << cc_path << std::endl;
-        const uint32_t N = s.N(), D = s.D(), L = s.L();
+        const uint32_t N = s.N(), L = s.L();
         const size_t batchSize = s.batch();
         std::cout << "[encrypt] Batch size from CryptoContext = " << batchSize << std::endl;
         std::vector<uint64_t> pk;
-        if (!read_key_file(pubkey_path, KIND_PK, N, D, 2, pk)) {
+        if (!load_public_key(s, pubkey_path, pk)) {
             std::cerr << "[encrypt] ERROR: Failed to deserialize public key from " << pubkey_path << std::endl;
             return 1;
         }

@@ -47,7 +47,7 @@ int main(int argc, char *argv[]) {
         std::vector<uint64_t> evks(n_pre * evk_words);
         for (size_t k = 0; k < n_pre; ++k) {
             std::vector<uint64_t> evk;
-            if (!read_key_file(rekey_paths[order[k]], KIND_RK, N, D, 2 * beta, evk)) {
+            if (!load_eval_key(s, rekey_paths[order[k]], evk)) {
                 std::cerr << "[round] ERROR: Failed to load ReKey from " << rekey_paths[order[k]] << std::endl;
                 return 1;
             }

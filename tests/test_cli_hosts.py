@@ -471,3 +471,105 @@ def test_malformed_client_ciphertexts_are_refused(tmp_path):
         assert r.returncode == 1 and "[agg] ERROR" in r.stderr, name
         r = run("serverRound", cc, tmp_path / "o.json", "-", tmp_path / "enc.json", tmp_path / "rk", bad)
         assert r.returncode == 1 and "[round] ERROR" in r.stderr, name
+
+
+def read_key_container(path):
+    """BlobHeader (48 bytes) + residues of a key container written by the hosts: (kind, ring_dim, limbs, parts, data)."""
+    import struct
+    raw = open(path, "rb").read()
+    magic, ver, kind, ring, limbs, parts = struct.unpack("<4sIIIII", raw[:24])
+    assert magic == b"MKCK" and ver == 1
+    data = np.frombuffer(raw[48:48 + 8 * ring * limbs * parts], dtype=np.uint64).reshape(parts, limbs, ring)
+    return kind, ring, limbs, parts, data
+
+
+def openfhe_style_dcrtpoly(limbs, moduli, fmt=0):
+    return {"cereal_class_version": 1, "f": fmt,
+            "v": [{"cereal_class_version": 1, "f": fmt,
+                   "v": {"polymorphic_id": 1073741824,
+                         "ptr_wrapper": {"valid": 1, "data": {"cereal_class_version": 1, "v": [int(x) for x in limb],
+                                                              "m": {"v": int(m)}}}}}
+                  for limb, m in zip(limbs, moduli)]}
+
+
+@pytest.mark.gpu
+def test_public_and_reencryption_keys_in_openfhe_json_form(tmp_path):
+    """SURVEY 8f row f2, the part without a reference fixture (PARITY UNPINNED: the reference's public-key and ReKey
+    blobs are missing): keys made by this project's programs are re-written in the nesting OpenFHE's JSON serialiser uses
+    for DCRTPoly elements (the private-key fixture's shape; PublicKeyImpl "h" = [b, a], EvalKeyRelinImpl "k" =
+    [A vector, B vector]) and must drive encryptModelWeights / REkeyGen / changeCipherDomain / serverRound exactly like
+    the containers they came from -- re-encryption is deterministic, so outputs are compared byte for byte."""
+    cc = _small_cc(tmp_path)
+    moduli_cc = json.load(open(cc))["mkckks_cc"]
+
+    def ok(r):
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r
+
+    for c in (1, 2):
+        ok(run("keyGen", cc, tmp_path / f"pk{c}", tmp_path / f"sk{c}"))
+    ok(run("REkeyGen", cc, tmp_path / "sk1", tmp_path / "pk2", tmp_path / "rk1"))
+    from ppqsflhe_amd import Context
+    g = Context(moduli_cc["log_n"], moduli_cc["MultiplicativeDepth"], moduli_cc["ScalingModSize"], moduli_cc["FirstModSize"],
+                dnum=moduli_cc["NumLargeDigits"], device=-1)
+    mods = [int(m) for m in g.moduli]
+    g.close()
+    # public key of client 2 and re-encryption key 1 -> 2 as OpenFHE-shaped JSON
+    kind, ring, limbs, parts, pk2 = read_key_container(tmp_path / "pk2")
+    assert (kind, parts, limbs) == (2, 2, len(mods))
+    pk_json = {"value0": {"polymorphic_id": 1073741824, "ptr_wrapper": {"id": 2147483649, "data": {
+        "cereal_class_version": 0, "h": [openfhe_style_dcrtpoly(pk2[0], mods), openfhe_style_dcrtpoly(pk2[1], mods)]}}}}
+    (tmp_path / "pk2.json").write_text(json.dumps(pk_json))
+    kind, ring, limbs, parts, rk = read_key_container(tmp_path / "rk1")
+    beta = parts // 2
+    assert kind == 4 and beta >= 2
+    rk_json = {"value0": {"polymorphic_id": 1073741824, "ptr_wrapper": {"id": 2147483649, "data": {
+        "cereal_class_version": 0,
+        "k": [[openfhe_style_dcrtpoly(rk[2 * d + 1], mods) for d in range(beta)],     # A vector
+              [openfhe_style_dcrtpoly(rk[2 * d], mods) for d in range(beta)]]}}}}     # B vector
+    (tmp_path / "rk1.json").write_text(json.dumps(rk_json))
+
+    vals = np.linspace(-0.25, 0.25, 300)
+    w = _weights(tmp_path, "w.json", [("l", vals)])
+    ok(run("encryptModelWeights", cc, tmp_path / "pk1", w, tmp_path / "enc1.json"))
+    # re-encryption key: JSON form == container form, byte for byte
+    ok(run("changeCipherDomain", cc, tmp_path / "rk1", tmp_path / "enc1.json", tmp_path / "a.json"))
+    r = ok(run("changeCipherDomain", cc, tmp_path / "rk1.json", tmp_path / "enc1.json", tmp_path / "b.json"))
+    assert "[recrypt] ReKey loaded" in r.stdout
+    assert open(tmp_path / "a.json").read() == open(tmp_path / "b.json").read()
+    ok(run("serverRound", cc, tmp_path / "c.json", tmp_path / "rk1.json", tmp_path / "enc1.json"))
+    ok(run("serverRound", cc, tmp_path / "d.json", tmp_path / "rk1", tmp_path / "enc1.json"))
+    assert open(tmp_path / "c.json").read() == open(tmp_path / "d.json").read()
+    # public key: encrypt under the JSON form, decrypt with the matching secret key
+    ok(run("encryptModelWeights", cc, tmp_path / "pk2.json", w, tmp_path / "enc2.json"))
+    ok(run("decryptModelWeights", cc, tmp_path / "sk2", tmp_path / "enc2.json", tmp_path / "dec2.json"))
+    got = np.array(json.load(open(tmp_path / "dec2.json"))["weights_summary"][0]["values"])
+    assert np.abs(got - vals).max() < 2.0 ** -25
+    # ... and as the peer key of REkeyGen: client 1's ciphertext, moved with that key, opens under client 2's secret
+    ok(run("REkeyGen", cc, tmp_path / "sk1", tmp_path / "pk2.json", tmp_path / "rk1b"))
+    ok(run("changeCipherDomain", cc, tmp_path / "rk1b", tmp_path / "enc1.json", tmp_path / "e.json"))
+    ok(run("decryptModelWeights", cc, tmp_path / "sk2", tmp_path / "e.json", tmp_path / "dec_e.json"))
+    got = np.array(json.load(open(tmp_path / "dec_e.json"))["weights_summary"][0]["values"])
+    assert np.abs(got - vals).max() < 2.0 ** -25
+    # COEFFICIENT-format elements on file ("f": 1) are transformed on import: same key, same output
+    from oracle.oracle import OracleContext
+    o = OracleContext(moduli_cc["log_n"], moduli_cc["MultiplicativeDepth"], moduli_cc["ScalingModSize"],
+                      moduli_cc["FirstModSize"], dnum=moduli_cc["NumLargeDigits"])
+    coef = lambda poly: [o.ntt_inv(i, poly[i]) for i in range(len(mods))]
+    rk_c = {"value0": {"ptr_wrapper": {"data": {
+        "k": [[openfhe_style_dcrtpoly(coef(rk[2 * d + 1]), mods, 1) for d in range(beta)],
+              [openfhe_style_dcrtpoly(coef(rk[2 * d]), mods, 1) for d in range(beta)]]}}}}
+    (tmp_path / "rk1c.json").write_text(json.dumps(rk_c))
+    ok(run("changeCipherDomain", cc, tmp_path / "rk1c.json", tmp_path / "enc1.json", tmp_path / "f.json"))
+    assert open(tmp_path / "f.json").read() == open(tmp_path / "a.json").read()
+    # tampering is refused: a residue at its modulus, a missing digit
+    bad = json.loads(json.dumps(rk_json))
+    bad["value0"]["ptr_wrapper"]["data"]["k"][0][0]["v"][0]["v"]["ptr_wrapper"]["data"]["v"][3] = mods[0]
+    (tmp_path / "bad1.json").write_text(json.dumps(bad))
+    r = run("changeCipherDomain", cc, tmp_path / "bad1.json", tmp_path / "enc1.json", tmp_path / "x.json")
+    assert r.returncode == 1 and "ERROR" in r.stderr
+    bad = json.loads(json.dumps(rk_json))
+    bad["value0"]["ptr_wrapper"]["data"]["k"][1].pop()
+    (tmp_path / "bad2.json").write_text(json.dumps(bad))
+    r = run("changeCipherDomain", cc, tmp_path / "bad2.json", tmp_path / "enc1.json", tmp_path / "x.json")
+    assert r.returncode == 1 and "ERROR" in r.stderr

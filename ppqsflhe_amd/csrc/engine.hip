@@ -903,12 +903,16 @@ static void launch_conv_col_m(const ConvIo &io, const ConvIo &iof, const dim3 &g
 }
 // srcmode: form of the sources in io.in (see src_is_double): 0 = packed 30-bit halves, 1 / 2 = doubles
 template <int LOG_H>
-static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, const Lanes &ln, int srcmode) {
+static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, const Lanes &ln, int srcmode,
+                              unsigned classes) {  // classes: bit 0 integer-class targets, bit 1 fp64-class targets
     const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
     ConvIo io = io0, iof = io0;
     io.target_mask = iof.target_mask = 0;
-    for (uint32_t j = 0; j < cv.n_out; ++j)
-        (T.h_fp_of[cv.dst_id[j]] ? iof.target_mask : io.target_mask) |= 1ull << j;
+    for (uint32_t j = 0; j < cv.n_out; ++j) {
+        const bool fp = T.h_fp_of[cv.dst_id[j]] != 0;
+        if (fp && (classes & 2)) iof.target_mask |= 1ull << j;
+        if (!fp && (classes & 1)) io.target_mask |= 1ull << j;
+    }
     io.nsel = (uint32_t)__builtin_popcountll(io.target_mask);
     iof.nsel = (uint32_t)__builtin_popcountll(iof.target_mask);
     const dim3 grid(io.items * tiles * io.nsel), gridf(io.items * tiles * iof.nsel);
@@ -924,11 +928,43 @@ static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevCo
         default: throw std::invalid_argument("base conversion fan-in unsupported");
     }
 }
-static bool launch_conv_col(const ConvIo &io, const NttTables &T, const DevConv &cv, const Lanes &s, int srcmode = 0) {
+// ModDown conversion summed over clients, fp64-class targets only (k_conv_col_sum); io.items = polynomials per client
+template <int LOG_H>
+static void launch_conv_col_sum_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, hipStream_t s) {
+    const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
+    ConvIo io = io0;
+    io.target_mask = 0;
+    for (uint32_t j = 0; j < cv.n_out; ++j)
+        if (T.h_fp_of[cv.dst_id[j]]) io.target_mask |= 1ull << j;
+    io.nsel = (uint32_t)__builtin_popcountll(io.target_mask);
+    if (!io.nsel) return;
+    const dim3 grid(io.items * tiles * io.nsel);
+    switch (cv.n_in) {
+        case 1: k_conv_col_sum<LOG_H, 1, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 2: k_conv_col_sum<LOG_H, 2, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 3: k_conv_col_sum<LOG_H, 3, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 4: k_conv_col_sum<LOG_H, 4, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 5: k_conv_col_sum<LOG_H, 5, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 6: k_conv_col_sum<LOG_H, 6, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 7: k_conv_col_sum<LOG_H, 7, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 8: k_conv_col_sum<LOG_H, 8, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        default: throw std::invalid_argument("base conversion fan-in unsupported");
+    }
+}
+static void launch_conv_col_sum(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s) {
     switch (fast_log_h(T.log_r1, 1u << T.log_r2)) {
-        case 4: launch_conv_col_h<4>(io, T, cv, s, srcmode); break;
-        case 3: launch_conv_col_h<3>(io, T, cv, s, srcmode); break;
-        case 2: launch_conv_col_h<2>(io, T, cv, s, srcmode); break;
+        case 4: launch_conv_col_sum_h<4>(io, T, cv, s); break;
+        case 3: launch_conv_col_sum_h<3>(io, T, cv, s); break;
+        default: throw std::logic_error("summed conversion needs 64- or 256-point columns");
+    }
+    MK_HIP(hipGetLastError());
+}
+static bool launch_conv_col(const ConvIo &io, const NttTables &T, const DevConv &cv, const Lanes &s, int srcmode = 0,
+                            unsigned classes = 3) {
+    switch (fast_log_h(T.log_r1, 1u << T.log_r2)) {
+        case 4: launch_conv_col_h<4>(io, T, cv, s, srcmode, classes); break;
+        case 3: launch_conv_col_h<3>(io, T, cv, s, srcmode, classes); break;
+        case 2: launch_conv_col_h<2>(io, T, cv, s, srcmode, classes); break;
         default: return false;
     }
     MK_HIP(hipGetLastError());
@@ -1455,7 +1491,9 @@ bool Engine::qsum_ok(uint32_t nl) const {
     if (!knobs_.qsum || !knobs_.fuse_inner || !knobs_.fuse_inner_int || !knobs_.fuse_p_inverse || !knobs_.sum_pair ||
         knobs_.row3x)
         return false;
-    if (fast_row(tabs_.log_r2, 1u << tabs_.log_r1) != 4 || fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) == 0) return false;
+    if (fast_row(tabs_.log_r2, 1u << tabs_.log_r1) != 4 || fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) < 3) return false;
+    for (uint32_t k = 0; k < ps_.K; ++k)
+        if (tabs_.h_fp_of[ps_.L + k]) return false;  // k_conv_col_sum takes the P limbs as packed integer sources
     for (uint32_t i = 0; i < nl; ++i)
         if (tabs_.h_fp_of[i]) return true;
     return false;
@@ -1485,13 +1523,15 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
     const size_t w_coef = (size_t)max_items * nl * n, w_dig = (size_t)max_items * nparts * ext * n;
     const size_t w_pc = (size_t)max_items * 2 * K * n, w_conv = (size_t)max_items * 2 * nl * n;
     const size_t w_til = (size_t)max_items * 2 * n_intq * n;
-    u64 *ws = workspace(w_coef + w_dig + w_pc + w_conv + w_til);
+    const size_t w_csum = (size_t)std::min(knobs_.chunk, n_ct) * 2 * nl * n;  // conversions summed over a group's clients
+    u64 *ws = workspace(w_coef + w_dig + w_pc + w_conv + w_til + w_csum);
     hipStream_t main = stream_;
     for (uint32_t b0 = 0; b0 < n_ct; b0 += knobs_.chunk) {
         const uint32_t cnt = std::min(knobs_.chunk, n_ct - b0);
         for (uint32_t g0 = 0; g0 < n_clients; g0 += group) {
             const uint32_t gc = std::min(group, n_clients - g0), items = gc * cnt;
-            u64 *coef = ws, *dig = coef + w_coef, *pc = dig + w_dig, *conv = pc + w_pc, *til = conv + w_conv;
+            u64 *coef = ws, *dig = coef + w_coef, *pc = dig + w_dig, *conv = pc + w_pc, *til = conv + w_conv,
+                *convsum = til + w_til;
             const u64 *ct0 = cts + ((size_t)g0 * n_ct + b0) * ct_words;  // client g0, index b0
             const u64 *c1 = ct0 + (size_t)nl * n, *evk0 = evks + (size_t)g0 * evk_words;
             const size_t ct_cstride = (size_t)n_ct * ct_words;
@@ -1513,7 +1553,23 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
                 ap.nsel = K;
                 launch_row3_inner_int_k<2, true>(ap, tabs_, nparts, ps_.L, pc, K, main);
             }
-            moddown_convert(nullptr, pc, conv, 2 * items, nl, true);
+            {   // ApproxModDown: inverse column pass of every item's P limbs (in place on pc), then the conversion
+                // P -> Q_l: fp64-class targets summed over the group's clients before ONE forward column pass
+                // (k_conv_col_sum), integer-class targets (q_0) per client as before
+                const u64 *fold = folded_scale(nl);
+                NttIo pin{pc, pc, (size_t)K * n, (size_t)K * n, 0, 0, nl, K, nl};
+                launch_col<true>(pin, tabs_, 2 * items, fold, fold + D, lanes(), 1);
+                MK_HIP(hipGetLastError());
+                const DevConv &cv = moddown_conv(nl);
+                ConvIo cs{pc, convsum, (size_t)K * n, (size_t)nl * n, 2 * cnt, 0, 0};
+                cs.n_clients = gc;
+                cs.in_cstride = (size_t)cnt * 2 * K * n;
+                launch_conv_col_sum(cs, tabs_, cv, main);
+                if (n_intq) {
+                    ConvIo ci{pc, conv, (size_t)K * n, (size_t)nl * n, 2 * items, 0, 0};
+                    launch_conv_col(ci, tabs_, cv, lanes(), 0, 1u);
+                }
+            }
             if (n_intq) {  // integer-class Q limbs: accumulators through a compact til
                 InnerArgs aq = ia;
                 aq.slot_mask = intq_mask;
@@ -1529,7 +1585,7 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
                 sa.til_compact = 1;
                 launch_row_tail_sum<4>(sa, tabs_, true, main, 1u);
             }
-            QSumArgs qa{dig, conv, ct0, evk0, out + (size_t)b0 * ct_words, pq, ct_cstride, ct_words, evk_words, ct_words,
+            QSumArgs qa{dig, convsum, ct0, evk0, out + (size_t)b0 * ct_words, pq, ct_cstride, ct_words, evk_words, ct_words,
                         gc, cnt, nl, ext, D, ps_.alpha, fp_mask, (uint32_t)__builtin_popcountll(fp_mask), g0 != 0 ? 1u : 0u};
             if (knobs_.qsum_geom == 2) launch_qsum_fp<4>(qa, tabs_, nparts, main);
             else launch_qsum3_fp<3>(qa, tabs_, nparts, main);

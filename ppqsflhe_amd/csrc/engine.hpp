@@ -54,7 +54,8 @@ struct Lanes {
 // measured best; every non-default value has a parity test (tests/test_gpu_parity.py).
 struct Knobs {
     uint32_t chunk = 16;         // MKCKKS_CHUNK: ciphertexts per workspace chunk
-    uint32_t qsum_group = 4;     // MKCKKS_QSUM_GROUP: clients per pass of the merged n-client flow (4: +1 % against 8)
+    uint32_t qsum_group = 8;     // MKCKKS_QSUM_GROUP: clients per pass of the merged n-client flow (one forward transform of
+                                 // the summed ModDown conversions per group: 8 is +2.7 % against 4, 2 is -6.6 %)
     int qsum_geom = 3;           // MKCKKS_QSUM_GEOM: 3 = three-round k_qsum3_fp (3 waves per SIMD), 2 = two-round k_qsum_fp
     bool generic_ntt = false;    // MKCKKS_GENERIC_NTT=1: LDS-stage kernels for both passes
     bool no_fp64 = false;        // MKCKKS_NO_FP64=1: integer arithmetic on every limb

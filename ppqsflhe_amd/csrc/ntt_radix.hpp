@@ -383,6 +383,9 @@ struct ConvIo {
     uint32_t items;
     unsigned long long target_mask;  // targets (indices into cv.dst_*) of this instance's arithmetic class
     uint32_t nsel;                   // popcount(target_mask)
+    // k_conv_col_sum: item i of client c is read at in + c * in_cstride + i * in_stride
+    uint32_t n_clients = 1;
+    size_t in_cstride = 0;
 };
 // canonical integer below 2^52 held in a double -> its 30-bit halves (what split30 gives for the u64)
 MK_D void split30_d(u64 dbl_bits, uint32_t &lo, uint32_t &hi) {
@@ -492,6 +495,81 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
         }
     }
     col_forward_finish<LOG_H, FP>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
+}
+
+// ApproxModDown's conversion P -> Q_l for an fp64-class target, SUMMED OVER CLIENTS before the forward transform:
+//   conv_sum[t] = sum_c ApproxSwitchCRTBasis_c[t]  (coefficient format, mod q_t),  then ONE forward column pass.
+// The reference transforms every client's conversion separately (ApproxModDown inside each ReEncrypt) and adds the
+// results afterwards (EvalAdd); the transform is linear over Z_{q_t}, so  sum_c NTT(conv_c) = NTT(sum_c conv_c)  residue
+// for residue -- each client's conversion is still computed on its own (the approximate conversion is NOT additive in
+// its input; only what follows it is linear).  n - 1 of the n forward transforms per (index, component, limb) disappear.
+// Sources: the K P-limbs of every client as packed 30-bit halves (integer class).
+template <int LOG_H, int N_IN, typename CONV>
+__global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_sum(ConvIo io, NttTables T, CONV cv) {
+    using TL = ColTile<LOG_H>;
+    constexpr int H = TL::H, S = TL::S;
+    __shared__ u64 lds[TL::WORDS];
+    const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
+    const uint32_t groups = io.items * tiles;
+    uint32_t grp, jt;
+    if (groups % 8 == 0) {  // the targets of one source tile: neighbours in one XCD's queue (see k_conv_col)
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / io.nsel) * 8 + xcd;
+        jt = qidx % io.nsel;
+    } else {
+        grp = blockIdx.x / io.nsel;
+        jt = blockIdx.x % io.nsel;
+    }
+    jt = nth_set_bit(io.target_mask, jt);
+    const uint32_t item = grp / tiles, tile = grp % tiles;
+    const uint32_t id = cv.dst_id[jt];
+    const LimbConst lc = T.limb[id];
+    if (!lc.fp) return;  // never: the host selects the fp64-class targets
+    const int c = threadIdx.x % S, j = threadIdx.x / S;
+    const u64 *src0 = io.in + (size_t)item * io.in_stride + tile * S + c;
+    u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jt] * n + tile * S + c;
+    uint32_t h0[N_IN], h1[N_IN];
+#pragma unroll
+    for (int i = 0; i < N_IN; ++i) split30(cv.hat[i * cv.n_out + jt], h0[i], h1[i]);
+    double sum[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) sum[k] = 0.0;
+#pragma unroll 1
+    for (uint32_t cl = 0; cl < io.n_clients; ++cl) {
+        const u64 *src = src0 + (size_t)cl * io.in_cstride;
+        // the H * N_IN load offsets do not depend on the client: left alone, the compiler computes all of them once in
+        // front of the loop and keeps 2 registers each alive across it (115 spilled registers at 4 waves per SIMD).
+        // Offsets derived from values that are opaque per iteration are recomputed where they are used instead.
+        uint32_t r2v = r2, nv = n;
+        asm volatile("" : "+s"(r2v), "+s"(nv));
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            u64 v;
+            if (N_IN <= 4) {
+                Cols acc{0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < N_IN; ++i) {
+                    const u64 p = src[cv.src_slot[i] * nv + (uint32_t)(j + H * k) * r2v];
+                    mac_cols(acc, (uint32_t)p, (uint32_t)(p >> 32), h0[i], h1[i]);
+                }
+                v = reduce_cols_lazy(acc, lc);  // < 4q < 2^53
+            } else {
+                Cols4 acc{0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < N_IN; ++i) {
+                    const u64 p = src[cv.src_slot[i] * nv + (uint32_t)(j + H * k) * r2v];
+                    mac_cols4(acc, (uint32_t)p, (uint32_t)(p >> 32), h0[i], h1[i]);
+                }
+                v = reduce_cols4(acc, lc);
+            }
+            // running sum kept below 0.51 q + 4 q: exact doubles
+            sum[k] = fp_reduce(sum[k] + (double)v, lc.qd, lc.qinv);
+        }
+    }
+    u64 x[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) x[k] = dbits(sum[k]);
+    col_forward_finish<LOG_H, true>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
 }
 
 // ApproxModDown tail folded into the copy-out of the forward row pass:

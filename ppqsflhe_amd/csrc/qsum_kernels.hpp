@@ -3,8 +3,9 @@
 // For a (ciphertext index b, Q limb t, row tile) the workgroup walks ALL clients c and, per client,
 //   * finishes the forward transform (row pass) of every converted ModUp digit d_j[t] and accumulates the eval-key
 //     inner products  d_j[t] * b_j[t],  d_j[t] * a_j[t]   (EvalFastKeySwitchCoreExt; the digit that owns t is c1 itself),
-//   * finishes the forward transform of ApproxModDown's converted limbs conv_0[t], conv_1[t] and subtracts them,
 //   * adds c0 * P (component 0),
+// then finishes the forward transform of ApproxModDown's converted limbs -- already summed over the clients in
+// coefficient format by k_conv_col_sum (the transform is linear) -- and subtracts them,
 // keeping the two running sums over digits AND clients in registers as exact doubles; after the last client one
 // multiplication by P^-1 gives  sum_c [ (ctilde_c - conv_c) * P^-1 (+ c0_c) ]  mod q_t, the coefficient-wise sum of the
 // clients' re-encryptions (ReEncrypt x n at changeCipherDomain.cpp:74 + the EvalAdd chain of
@@ -18,16 +19,9 @@
 
 namespace mk {
 
-#ifndef MK_QSUM_XN
-#define MK_QSUM_XN 0  // 1: inputs of transform u+1 requested before transform u starts (32 more registers): measured -0.5 %
-#endif
-#ifndef MK_QSUM_TWREG
-#define MK_QSUM_TWREG 1
-#endif
-
 struct QSumArgs {
     const u64 *dig;    // [client][cnt][nparts][ext][N] column-passed converted digits (doubles on fp64-class limbs)
-    const u64 *conv;   // [client][cnt][2][nl][N]       column-passed ModDown conversions
+    const u64 *conv;   // [cnt][2][nl][N]  column-passed ModDown conversions SUMMED over the clients (k_conv_col_sum)
     const u64 *cts;    // input ciphertexts: client c, index i at cts + c * ct_cstride + i * ct_stride, [2][nl][N]
     const u64 *evk;    // client c at evk + c * evk_cstride: [nparts][2][D][N]
     u64 *out;          // index i at out + i * ct_stride_out: [2][nl][N]
@@ -86,24 +80,45 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_qsum_fp(QSumArgs a, NttTable
             acc1[i] = double2{0.0, 0.0};
         }
     }
-    // transform u of client c: u < ND converted digits (owning digit skipped), then the two ModDown conversions
+    // transform u of client c: u < ND converted digits (owning digit skipped); after the last client the two summed
+    // ModDown conversions (client index n_clients, u = 0, 1)
     const size_t th_off = tile_off + (size_t)g * R + j;
     auto src_of = [&](uint32_t c, int u) -> const u64 * {
-        const size_t item = (size_t)c * a.cnt + b;
-        if (u < ND) {
+        if (c < a.n_clients && ND > 0) {
+            const size_t item = (size_t)c * a.cnt + b;
             const int dj = u < own ? u : u + 1;
             return a.dig + ((item * NPARTS + dj) * a.ext + sl) * n + th_off;
         }
-        return a.conv + ((item * 2 + (u - ND)) * a.nl + sl) * n + th_off;
+        return a.conv + (((size_t)b * 2 + u) * a.nl + sl) * n + th_off;
     };
-    // round-B twiddles of this thread: the same for every transform of the kernel (one limb, one row); with
-    // MK_QSUM_TWREG they stay in registers instead of being re-read from L2 per transform (60 registers against
-    // 15 x 16-byte loads per transform)
-    u64 w2[H - 1], wp2[H - 1];
-    if (MK_QSUM_TWREG) load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
+    // one forward row transform of x[] (inputs in registers), results reduced to |y| <= 0.51 q in this wave's LDS rows;
+    // `next` (may be null): inputs of the following transform, requested while this one's results are consumed
+    auto transform = [&](u64 (&x)[H], const u64 *next) {
+        {
+            u64 w[H - 1], wp[H - 1];
+            wave_lds_sync();  // twiddles staged (first transform) / previous transform's consumers finished with LDS
+            TA::fetch(twa, twa_sh, g, w, wp);
+            radix_forward_fp<LOG_H>(x, w, wp, q, qinv);
+        }
+        u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
+        load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
+        radix_forward_fp<LOG_H>(x, w2, wp2, q, qinv);
+#pragma unroll
+        for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));  // |y| <= 0.51 q
+        if (next) {
+#pragma unroll
+            for (int k = 0; k < H; ++k) x[k] = ld_stream(next + H * k);
+        }
+        wave_lds_sync();
+    };
     u64 x[H];
     {
-        const u64 *src = src_of(0, 0);
+        const u64 *src = src_of(ND > 0 ? 0 : a.n_clients, 0);
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = ld_stream(src + H * k);
     }
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_qsum_fp(QSumArgs a, NttTable
                 acc0[i].y += fp_mulmod_any(yz, u52_to_double(bb.y), q, qinv) + fp_mulmod(u52_to_double(zz.y), pm, pmq, q);
                 acc1[i].x += fp_mulmod_any(yx, u52_to_double(aa.x), q, qinv);
                 acc1[i].y += fp_mulmod_any(yz, u52_to_double(aa.y), q, qinv);
-                if (NPARTS > 4) {  // keeps the sums below 2^53 for up to 6 digits (see the bound below)
+                if (NPARTS > 4 || ND == 0) {  // keeps the sums below 2^53 (see the bound below)
                     acc0[i].x = fp_reduce(acc0[i].x, q, qinv);
                     acc0[i].y = fp_reduce(acc0[i].y, q, qinv);
                     acc1[i].x = fp_reduce(acc1[i].x, q, qinv);
@@ -135,81 +150,49 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_qsum_fp(QSumArgs a, NttTable
             }
         }
 #pragma unroll 1
-        for (int u = 0; u < ND + 2; ++u) {
-            // the NEXT transform's inputs are requested before this one starts: their latency runs under two rounds of
-            // butterflies and the products (two transforms' inputs are in registers at a time)
-            u64 xn[H];
-            if (MK_QSUM_XN) {
-                const bool last_u = u == ND + 1;
-                if (!last_u || c + 1 < a.n_clients) {
-                    const u64 *src = last_u ? src_of(c + 1, 0) : src_of(c, u + 1);
+        for (int u = 0; u < ND; ++u) {
+            const bool last_u = u == ND - 1;
+            transform(x, last_u ? src_of(c + 1, 0) : src_of(c, u + 1));
+            const int dj = u < own ? u : u + 1;
+            const u64 *e0 = ek + ((size_t)dj * 2 + 0) * a.D * n, *e1 = ek + ((size_t)dj * 2 + 1) * a.D * n;
+            // per client the sums grow by at most 0.97 q (own digit) + 0.82 q (c0 P) + 0.75 q per converted digit on top
+            // of the 0.51 q carried over: < 3.8 q < 2^53 for up to 4 digits (5, 6 digits: the extra reduction above);
+            // the last digit's products end with the reduction that brings them back to 0.51 q
 #pragma unroll
-                    for (int k = 0; k < H; ++k) xn[k] = ld_stream(src + H * k);
-                }
-            }
-            {
-                u64 w[H - 1], wp[H - 1];
-                wave_lds_sync();  // twiddles staged (first transform) / previous transform's consumers finished with LDS
-                TA::fetch(twa, twa_sh, g, w, wp);
-                radix_forward_fp<LOG_H>(x, w, wp, q, qinv);
-            }
-            if (!MK_QSUM_TWREG) load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);  // requested before the exchange
-#pragma unroll
-            for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
-            wave_lds_sync();
-#pragma unroll
-            for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
-            radix_forward_fp<LOG_H>(x, w2, wp2, q, qinv);
-#pragma unroll
-            for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));  // |y| <= 0.51 q
-            if (MK_QSUM_XN) {
-#pragma unroll
-                for (int k = 0; k < H; ++k) x[k] = xn[k];
-            } else {  // requested while this transform's results are consumed
-                const bool last_u = u == ND + 1;
-                if (!last_u || c + 1 < a.n_clients) {
-                    const u64 *src = last_u ? src_of(c + 1, 0) : src_of(c, u + 1);
-#pragma unroll
-                    for (int k = 0; k < H; ++k) x[k] = ld_stream(src + H * k);
-                }
-            }
-            wave_lds_sync();
-            if (u < ND) {
-                const int dj = u < own ? u : u + 1;
-                const u64 *e0 = ek + ((size_t)dj * 2 + 0) * a.D * n, *e1 = ek + ((size_t)dj * 2 + 1) * a.D * n;
-#pragma unroll
-                for (int i = 0; i < PAIRS; ++i) {
-                    const int e = wave_pair<LOG_H>(i);
-                    const int gg = (2 * e) / R, xx = (2 * e) % R;
-                    const ulong2 bb = reinterpret_cast<const ulong2 *>(e0)[e];
-                    const ulong2 aa = reinterpret_cast<const ulong2 *>(e1)[e];
-                    const double yx = bitsd(lds[TL::at(gg, xx)]), yz = bitsd(lds[TL::at(gg, xx + 1)]);
-                    acc0[i].x += fp_mulmod_any(yx, u52_to_double(bb.x), q, qinv);
-                    acc0[i].y += fp_mulmod_any(yz, u52_to_double(bb.y), q, qinv);
-                    acc1[i].x += fp_mulmod_any(yx, u52_to_double(aa.x), q, qinv);
-                    acc1[i].y += fp_mulmod_any(yz, u52_to_double(aa.y), q, qinv);
-                }
-            } else if (u == ND) {
-#pragma unroll
-                for (int i = 0; i < PAIRS; ++i) {
-                    const int e = wave_pair<LOG_H>(i);
-                    const int gg = (2 * e) / R, xx = (2 * e) % R;
-                    acc0[i].x -= bitsd(lds[TL::at(gg, xx)]);
-                    acc0[i].y -= bitsd(lds[TL::at(gg, xx + 1)]);
-                }
-            } else {
-                // per client the sums grow by at most 0.97 q (own digit) + 0.82 q (c0 P) + 0.75 q per converted digit +
-                // 0.51 q (conversion) on top of the 0.51 q carried over: < 4.4 q < 2^53 for up to 4 digits (5, 6 digits:
-                // the extra reduction above); one reduction per client brings them back to 0.51 q
-#pragma unroll
-                for (int i = 0; i < PAIRS; ++i) {
-                    const int e = wave_pair<LOG_H>(i);
-                    const int gg = (2 * e) / R, xx = (2 * e) % R;
-                    acc1[i].x = fp_reduce(acc1[i].x - bitsd(lds[TL::at(gg, xx)]), q, qinv);
-                    acc1[i].y = fp_reduce(acc1[i].y - bitsd(lds[TL::at(gg, xx + 1)]), q, qinv);
+            for (int i = 0; i < PAIRS; ++i) {
+                const int e = wave_pair<LOG_H>(i);
+                const int gg = (2 * e) / R, xx = (2 * e) % R;
+                const ulong2 bb = reinterpret_cast<const ulong2 *>(e0)[e];
+                const ulong2 aa = reinterpret_cast<const ulong2 *>(e1)[e];
+                const double yx = bitsd(lds[TL::at(gg, xx)]), yz = bitsd(lds[TL::at(gg, xx + 1)]);
+                acc0[i].x += fp_mulmod_any(yx, u52_to_double(bb.x), q, qinv);
+                acc0[i].y += fp_mulmod_any(yz, u52_to_double(bb.y), q, qinv);
+                acc1[i].x += fp_mulmod_any(yx, u52_to_double(aa.x), q, qinv);
+                acc1[i].y += fp_mulmod_any(yz, u52_to_double(aa.y), q, qinv);
+                if (last_u) {
                     acc0[i].x = fp_reduce(acc0[i].x, q, qinv);
                     acc0[i].y = fp_reduce(acc0[i].y, q, qinv);
+                    acc1[i].x = fp_reduce(acc1[i].x, q, qinv);
+                    acc1[i].y = fp_reduce(acc1[i].y, q, qinv);
                 }
+            }
+        }
+    }
+    // ApproxModDown's conversions, summed over the clients: two transforms, subtracted (|acc| <= 0.51 q + 0.51 q)
+#pragma unroll 1
+    for (int comp = 0; comp < 2; ++comp) {
+        transform(x, comp == 0 ? src_of(a.n_clients, 1) : nullptr);
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int e = wave_pair<LOG_H>(i);
+            const int gg = (2 * e) / R, xx = (2 * e) % R;
+            const double yx = bitsd(lds[TL::at(gg, xx)]), yz = bitsd(lds[TL::at(gg, xx + 1)]);
+            if (comp == 0) {
+                acc0[i].x -= yx;
+                acc0[i].y -= yz;
+            } else {
+                acc1[i].x -= yx;
+                acc1[i].y -= yz;
             }
         }
     }
@@ -285,16 +268,27 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
     }
     const size_t th_off = tile_off + (size_t)c.g * R + c.t;
     auto src_of = [&](uint32_t cl, int u) -> const u64 * {
-        const size_t item = (size_t)cl * a.cnt + b;
-        if (u < ND) {
+        if (cl < a.n_clients && ND > 0) {
+            const size_t item = (size_t)cl * a.cnt + b;
             const int dj = u < own ? u : u + 1;
             return a.dig + ((item * NPARTS + dj) * a.ext + sl) * n + th_off;
         }
-        return a.conv + ((item * 2 + (u - ND)) * a.nl + sl) * n + th_off;
+        return a.conv + (((size_t)b * 2 + u) * a.nl + sl) * n + th_off;
+    };
+    auto transform = [&](u64 (&x)[8], const u64 *next) {
+        wave_lds_sync();  // previous transform's consumers finished reading this wave's rows
+        row3_forward<true, LOGC>(x, c, wc, wpc, lc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 8 * c.t + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));
+        if (next) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = ld_stream(next + TPR * k);
+        }
+        wave_lds_sync();
     };
     u64 x[8];
     {
-        const u64 *src = src_of(0, 0);
+        const u64 *src = src_of(ND > 0 ? 0 : a.n_clients, 0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + TPR * k);
     }
@@ -318,7 +312,7 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
                 acc0[i].y += fp_mulmod_any(yz, u52_to_double(bb.y), q, qinv) + fp_mulmod(u52_to_double(zz.y), pm, pmq, q);
                 acc1[i].x += fp_mulmod_any(yx, u52_to_double(aa.x), q, qinv);
                 acc1[i].y += fp_mulmod_any(yz, u52_to_double(aa.y), q, qinv);
-                if (NPARTS > 4) {
+                if (NPARTS > 4 || ND == 0) {
                     acc0[i].x = fp_reduce(acc0[i].x, q, qinv);
                     acc0[i].y = fp_reduce(acc0[i].y, q, qinv);
                     acc1[i].x = fp_reduce(acc1[i].x, q, qinv);
@@ -327,51 +321,44 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
             }
         }
 #pragma unroll 1
-        for (int u = 0; u < ND + 2; ++u) {
-            wave_lds_sync();  // previous transform's consumers finished reading this wave's rows
-            row3_forward<true, LOGC>(x, c, wc, wpc, lc);
+        for (int u = 0; u < ND; ++u) {
+            const bool last_u = u == ND - 1;
+            transform(x, last_u ? src_of(cl + 1, 0) : src_of(cl, u + 1));
+            const int dj = u < own ? u : u + 1;
+            const u64 *e0 = ek + ((size_t)dj * 2 + 0) * a.D * n, *e1 = ek + ((size_t)dj * 2 + 1) * a.D * n;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 8 * c.t + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));
-            {
-                const bool last_u = u == ND + 1;
-                if (!last_u || cl + 1 < a.n_clients) {
-                    const u64 *src = last_u ? src_of(cl + 1, 0) : src_of(cl, u + 1);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + TPR * k);
-                }
-            }
-            wave_lds_sync();
-            if (u < ND) {
-                const int dj = u < own ? u : u + 1;
-                const u64 *e0 = ek + ((size_t)dj * 2 + 0) * a.D * n, *e1 = ek + ((size_t)dj * 2 + 1) * a.D * n;
-#pragma unroll
-                for (int i = 0; i < PAIRS; ++i) {
-                    const int e = row3_pair<LOGC>(c.g, c.t, i);
-                    const int xx = (2 * e) % R;
-                    const ulong2 bb = reinterpret_cast<const ulong2 *>(e0)[e];
-                    const ulong2 aa = reinterpret_cast<const ulong2 *>(e1)[e];
-                    const double yx = bitsd(lds[TL::at(c.g, xx)]), yz = bitsd(lds[TL::at(c.g, xx + 1)]);
-                    acc0[i].x += fp_mulmod_any(yx, u52_to_double(bb.x), q, qinv);
-                    acc0[i].y += fp_mulmod_any(yz, u52_to_double(bb.y), q, qinv);
-                    acc1[i].x += fp_mulmod_any(yx, u52_to_double(aa.x), q, qinv);
-                    acc1[i].y += fp_mulmod_any(yz, u52_to_double(aa.y), q, qinv);
-                }
-            } else if (u == ND) {
-#pragma unroll
-                for (int i = 0; i < PAIRS; ++i) {
-                    const int xx = (2 * row3_pair<LOGC>(c.g, c.t, i)) % R;
-                    acc0[i].x -= bitsd(lds[TL::at(c.g, xx)]);
-                    acc0[i].y -= bitsd(lds[TL::at(c.g, xx + 1)]);
-                }
-            } else {  // bounds: see k_qsum_fp
-#pragma unroll
-                for (int i = 0; i < PAIRS; ++i) {
-                    const int xx = (2 * row3_pair<LOGC>(c.g, c.t, i)) % R;
-                    acc1[i].x = fp_reduce(acc1[i].x - bitsd(lds[TL::at(c.g, xx)]), q, qinv);
-                    acc1[i].y = fp_reduce(acc1[i].y - bitsd(lds[TL::at(c.g, xx + 1)]), q, qinv);
+            for (int i = 0; i < PAIRS; ++i) {  // bounds: see k_qsum_fp
+                const int e = row3_pair<LOGC>(c.g, c.t, i);
+                const int xx = (2 * e) % R;
+                const ulong2 bb = reinterpret_cast<const ulong2 *>(e0)[e];
+                const ulong2 aa = reinterpret_cast<const ulong2 *>(e1)[e];
+                const double yx = bitsd(lds[TL::at(c.g, xx)]), yz = bitsd(lds[TL::at(c.g, xx + 1)]);
+                acc0[i].x += fp_mulmod_any(yx, u52_to_double(bb.x), q, qinv);
+                acc0[i].y += fp_mulmod_any(yz, u52_to_double(bb.y), q, qinv);
+                acc1[i].x += fp_mulmod_any(yx, u52_to_double(aa.x), q, qinv);
+                acc1[i].y += fp_mulmod_any(yz, u52_to_double(aa.y), q, qinv);
+                if (last_u) {
                     acc0[i].x = fp_reduce(acc0[i].x, q, qinv);
                     acc0[i].y = fp_reduce(acc0[i].y, q, qinv);
+                    acc1[i].x = fp_reduce(acc1[i].x, q, qinv);
+                    acc1[i].y = fp_reduce(acc1[i].y, q, qinv);
                 }
+            }
+        }
+    }
+#pragma unroll 1
+    for (int comp = 0; comp < 2; ++comp) {  // the summed ModDown conversions
+        transform(x, comp == 0 ? src_of(a.n_clients, 1) : nullptr);
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int xx = (2 * row3_pair<LOGC>(c.g, c.t, i)) % R;
+            const double yx = bitsd(lds[TL::at(c.g, xx)]), yz = bitsd(lds[TL::at(c.g, xx + 1)]);
+            if (comp == 0) {
+                acc0[i].x -= yx;
+                acc0[i].y -= yz;
+            } else {
+                acc1[i].x -= yx;
+                acc1[i].y -= yz;
             }
         }
     }

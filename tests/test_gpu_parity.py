@@ -386,7 +386,7 @@ def test_reencrypt_sum(ctxs, name, nl, C, B):
                                  {"MKCKKS_QSUM": "0"},            # per-client key switch on two lanes + k_row_tail_sum2
                                  {"MKCKKS_QSUM": "0", "MKCKKS_SUM_ONE_LANE": "1"},
                                  {"MKCKKS_QSUM_GROUP": "2"},      # merged flow, clients in groups of 2 (running sum in out)
-                                 {"MKCKKS_QSUM_GROUP": "8"},
+                                 {"MKCKKS_QSUM_GROUP": "1"},
                                  {"MKCKKS_QSUM_GEOM": "2"},       # two-round k_qsum_fp (16 words per thread)
                                  {"MKCKKS_QSUM_GEOM": "2", "MKCKKS_QSUM_GROUP": "2"},
                                  {"MKCKKS_SUM_ONE_LANE": "1"}])   # clients strictly one after the other

@@ -481,7 +481,7 @@ Knobs Knobs::from_env() {
     }
     if (const char *e = std::getenv("MKCKKS_QSUM_GEOM")) {
         const int v = std::atoi(e);
-        if (v == 2 || v == 3) k.qsum_geom = v;
+        if (v == 2 || v == 3 || v == 4) k.qsum_geom = v;
     }
     k.generic_ntt = env_flag("MKCKKS_GENERIC_NTT", k.generic_ntt);
     k.no_fp64 = env_flag("MKCKKS_NO_FP64", k.no_fp64);
@@ -1588,6 +1588,7 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
             QSumArgs qa{dig, convsum, ct0, evk0, out + (size_t)b0 * ct_words, pq, ct_cstride, ct_words, evk_words, ct_words,
                         gc, cnt, nl, ext, D, ps_.alpha, fp_mask, (uint32_t)__builtin_popcountll(fp_mask), g0 != 0 ? 1u : 0u};
             if (knobs_.qsum_geom == 2) launch_qsum_fp<4>(qa, tabs_, nparts, main);
+            else if (knobs_.qsum_geom == 4) launch_qsum3_fp<2>(qa, tabs_, nparts, main);
             else launch_qsum3_fp<3>(qa, tabs_, nparts, main);
             MK_HIP(hipGetLastError());
         }

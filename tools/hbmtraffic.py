@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Per-kernel HBM traffic of one bench step from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs).
 
-usage: tools/hbmtraffic.py <fetch_dir> <write_dir> <units_per_step> [json_key] > profiles/rNN_pmc_hbm.txt
-bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: gfx950 FETCH_SIZE reports half of wide coalesced reads
-(MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are counted.  With json_key the per-step total is also
-written to profiles/hbm_traffic.json (read by bench.py for roofline.traffic)."""
+usage: tools/hbmtraffic.py <fetch_dir> <write_dir> <units_per_step> [json_key [profile_tag]] > profiles/rNN_pmc_hbm.txt
+bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 for every kernel: gfx950 FETCH_SIZE reports half of the bytes read, for the
+16-byte coalesced shape (MI355X_MICROARCH.md, HBM section) and -- calibrated on a known byte count,
+profiles/r02_calib_fetch.txt -- for this library's 8-byte row and column shapes alike; WRITE_SIZE is exact;
+Infinity-Cache hits are counted.  With json_key the per-step total is also written to profiles/hbm_traffic.json (read by
+bench.py for roofline.traffic, labelled there as a builder-run profile)."""
 import csv, glob, json, os, re, sys
 
 
@@ -36,8 +38,9 @@ if len(sys.argv) > 4:
     p = os.path.join(root, "profiles", "hbm_traffic.json")
     rec = json.load(open(p)) if os.path.exists(p) else {}
     rec[sys.argv[4]] = {"hbm_bytes_per_step": total, "units_per_step": units, "fetch_size_kib": tf, "write_size_kib": tw,
+                        "profile": "profiles/" + (sys.argv[5] if len(sys.argv) > 5 else "rNN") + "_pmc_hbm.txt",
                         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 "
                                   "--warmup 0 --no-cpu` (mk:: kernels only); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 "
-                                  "FETCH_SIZE reports half of wide coalesced reads (MI355X_MICROARCH.md HBM section); "
-                                  "Infinity-Cache hits are counted"}
+                                  "FETCH_SIZE reports half of the bytes read, calibrated for this library's 8- and 16-byte "
+                                  "shapes in profiles/r02_calib_fetch.txt; Infinity-Cache hits are counted"}
     json.dump(rec, open(p, "w"), indent=1)

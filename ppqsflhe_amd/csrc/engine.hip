@@ -1455,17 +1455,17 @@ static void launch_qsum_fp(const QSumArgs &a, const NttTables &T, uint32_t npart
     }
 }
 
-template <int MINW>
+template <int LOGC, int MINW>
 static void launch_qsum3_fp(const QSumArgs &a, const NttTables &T, uint32_t nparts, hipStream_t s) {
-    const uint32_t tiles = (1u << T.log_r1) / RowT<2>::ROWS;
+    const uint32_t tiles = (1u << T.log_r1) / RowT<LOGC>::ROWS;
     const dim3 grid(tiles * a.nsel * a.cnt);
     switch (nparts) {
-        case 1: k_qsum3_fp<1, 2, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 2: k_qsum3_fp<2, 2, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 3: k_qsum3_fp<3, 2, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 4: k_qsum3_fp<4, 2, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 5: k_qsum3_fp<5, 2, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 6: k_qsum3_fp<6, 2, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 1: k_qsum3_fp<1, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 2: k_qsum3_fp<2, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 3: k_qsum3_fp<3, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 4: k_qsum3_fp<4, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 5: k_qsum3_fp<5, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 6: k_qsum3_fp<6, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
         default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
     }
 }
@@ -1485,13 +1485,14 @@ const u64 *Engine::p_doubles() {
     return limb_vector("p_doubles", v);
 }
 
-// the merged n-client flow needs: radix column kernels, 256-point two-round row kernels (k_qsum_fp, k_row3_inner_int,
-// k_row_tail_sum2 exist for them), fp64-class Q limbs, and the fused integer inner product
+// the merged n-client flow needs: radix column kernels (64- or 256-point columns), 256- or 512-point rows (k_qsum3_fp,
+// k_row3_inner_int and the fused tail + sum kernels exist for them), fp64-class Q limbs, integer-class P limbs
 bool Engine::qsum_ok(uint32_t nl) const {
     if (!knobs_.qsum || !knobs_.fuse_inner || !knobs_.fuse_inner_int || !knobs_.fuse_p_inverse || !knobs_.sum_pair ||
         knobs_.row3x)
         return false;
-    if (fast_row(tabs_.log_r2, 1u << tabs_.log_r1) != 4 || fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) < 3) return false;
+    const int row_h = fast_row(tabs_.log_r2, 1u << tabs_.log_r1);
+    if ((row_h != 4 && row_h != 9) || fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) < 3) return false;
     for (uint32_t k = 0; k < ps_.K; ++k)
         if (tabs_.h_fp_of[ps_.L + k]) return false;  // k_conv_col_sum takes the P limbs as packed integer sources
     for (uint32_t i = 0; i < nl; ++i)
@@ -1516,6 +1517,7 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
     for (uint32_t i = nl; i < ext; ++i) p_mask |= 1ull << i;
     const uint32_t n_intq = (uint32_t)__builtin_popcountll(intq_mask);
     const uint32_t group = std::min(n_clients, knobs_.qsum_group);
+    const bool wide_rows = fast_row(tabs_.log_r2, 1u << tabs_.log_r1) == 9;  // N = 2^17: 512-point rows, three-round kernels
     // One stream: running the memory-bound sums of group g on a second stream beside the multiply-bound phases of group
     // g+1 was measured neutral to slightly negative (20.47 k against 20.59 k ct/s at groups of 4): both kinds of kernel
     // fill the register file of a CU, so the hardware time-slices them instead of co-scheduling.
@@ -1551,7 +1553,8 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
                 InnerArgs ap = ia;
                 ap.slot_mask = p_mask;
                 ap.nsel = K;
-                launch_row3_inner_int_k<2, true>(ap, tabs_, nparts, ps_.L, pc, K, main);
+                if (wide_rows) launch_row3_inner_int_k<3, true>(ap, tabs_, nparts, ps_.L, pc, K, main);
+                else launch_row3_inner_int_k<2, true>(ap, tabs_, nparts, ps_.L, pc, K, main);
             }
             {   // ApproxModDown: inverse column pass of every item's P limbs (in place on pc), then the conversion
                 // P -> Q_l: fp64-class targets summed over the group's clients before ONE forward column pass
@@ -1575,7 +1578,8 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
                 aq.slot_mask = intq_mask;
                 aq.nsel = n_intq;
                 aq.til_compact = 1;
-                launch_row3_inner_int_k<2, false>(aq, tabs_, nparts, ps_.L, nullptr, K, main);
+                if (wide_rows) launch_row3_inner_int_k<3, false>(aq, tabs_, nparts, ps_.L, nullptr, K, main);
+                else launch_row3_inner_int_k<2, false>(aq, tabs_, nparts, ps_.L, nullptr, K, main);
             }
             MK_HIP(hipGetLastError());
             if (n_intq) {  // q_0: forward row pass of the ModDown conversion + tail + sum over the group's clients
@@ -1583,13 +1587,15 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
                            (size_t)cnt * 2 * nl * n, (size_t)cnt * 2 * n_intq * n, ct_cstride, ct_words,
                            gc, nl, n_intq, 2 * cnt, 0, 0, g0 != 0 ? 1u : 0u};
                 sa.til_compact = 1;
-                launch_row_tail_sum<4>(sa, tabs_, true, main, 1u);
+                if (wide_rows) launch_row3_tail_sum<3>(sa, tabs_, main, 1u);
+                else launch_row_tail_sum<4>(sa, tabs_, true, main, 1u);
             }
             QSumArgs qa{dig, convsum, ct0, evk0, out + (size_t)b0 * ct_words, pq, ct_cstride, ct_words, evk_words, ct_words,
                         gc, cnt, nl, ext, D, ps_.alpha, fp_mask, (uint32_t)__builtin_popcountll(fp_mask), g0 != 0 ? 1u : 0u};
-            if (knobs_.qsum_geom == 2) launch_qsum_fp<4>(qa, tabs_, nparts, main);
-            else if (knobs_.qsum_geom == 4) launch_qsum3_fp<2>(qa, tabs_, nparts, main);
-            else launch_qsum3_fp<3>(qa, tabs_, nparts, main);
+            if (wide_rows) launch_qsum3_fp<3, 3>(qa, tabs_, nparts, main);
+            else if (knobs_.qsum_geom == 2) launch_qsum_fp<4>(qa, tabs_, nparts, main);
+            else if (knobs_.qsum_geom == 4) launch_qsum3_fp<2, 2>(qa, tabs_, nparts, main);
+            else launch_qsum3_fp<2, 3>(qa, tabs_, nparts, main);
             MK_HIP(hipGetLastError());
         }
     }

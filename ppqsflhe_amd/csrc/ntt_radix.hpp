@@ -1399,7 +1399,8 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_sum(SumArgs a, Ntt
             for (int k = 0; k < 8; ++k) x[k] = ld_stream(nxt + TPR * k);
         }
         wave_lds_sync();
-        const u64 *tq = a.til + (size_t)cl * a.til_cstride + ((size_t)poly * a.ext + sl) * n + tile_off;
+        const u64 *tq = a.til + (size_t)cl * a.til_cstride +
+                        ((size_t)poly * a.ext + (a.til_compact ? grp / tiles : sl)) * n + tile_off;
         const u64 *c0 = (poly & 1) == 0
                             ? a.cts + (size_t)cl * a.ct_cstride + (size_t)(poly >> 1) * a.ct_stride + (size_t)sl * n + tile_off
                             : nullptr;

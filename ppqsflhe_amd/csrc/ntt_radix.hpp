@@ -264,10 +264,30 @@ MK_D void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// The ownership invariants that make the wave-level hand-off legal, checked at compile time for every tile geometry the
+// row kernels instantiate.  A row of R = H*H words is transformed by H threads with consecutive thread ids, so
+//   (1) a wavefront holds whole rows in BOTH rounds:            64 % H == 0, rows per wave RW = 64 / H >= 1;
+//   (2) the copy-in / copy-out phases use the SAME ownership:   wave w touches pairs [w * PER_WAVE, (w+1) * PER_WAVE) with
+//       PER_WAVE = RW * R / 2 = exactly the pairs of rows [w * RW, (w+1) * RW), and PAIRS * 64 == PER_WAVE, i.e. the
+//       PAIRS accesses of wave_pair() cover the wave's rows once and nothing else;
+//   (3) the workgroup is a whole number of wavefronts and of rows: NTT_THREADS % 64 == 0, S * H == NTT_THREADS.
+// Hence no LDS word of the tile is read or written by two different waves, and within one wave DS operations execute in
+// program order (an ISA property of CDNA, not of the HIP language): wave_lds_sync() only has to stop the COMPILER from
+// moving LDS accesses across it.  The round-A twiddle area is the one shared region: every wave stages and reads only the
+// entries of its own rows (stage_twiddles_wave), same argument.
+template <int LOG_H>
+struct WaveOwnership {
+    static constexpr int H = 1 << LOG_H, R = H * H, S = 256 / H, RW = 64 / H;
+    static constexpr int PER_WAVE = RW * R / 2, PAIRS = S * R / 2 / NTT_THREADS;
+    static_assert(64 % H == 0 && RW >= 1, "a wavefront must hold whole rows");
+    static_assert(NTT_THREADS % 64 == 0 && S * H == NTT_THREADS, "workgroup = whole wavefronts = whole rows");
+    static_assert(PAIRS * 64 == PER_WAVE, "wave_pair() must cover exactly the wave's own rows");
+    static_assert((NTT_THREADS / 64) * RW == S, "the waves' row ranges partition the tile");
+};
 // i-th 16-byte access (pair of words, index into the tile's pairs) of this lane inside its wave's rows
 template <int LOG_H>
 MK_D int wave_pair(int i) {
-    constexpr int PER_WAVE = (64 >> LOG_H) * (1 << (2 * LOG_H)) / 2;
+    constexpr int PER_WAVE = WaveOwnership<LOG_H>::PER_WAVE;
     return (int)(threadIdx.x / 64) * PER_WAVE + (int)(threadIdx.x % 64) + 64 * i;
 }
 // round-A twiddles of this wave's rows only (same LDS layout as RowTwA::stage; RW = 64/H rows per wave)

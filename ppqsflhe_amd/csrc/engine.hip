@@ -928,26 +928,31 @@ static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevCo
         default: throw std::invalid_argument("base conversion fan-in unsupported");
     }
 }
-// ModDown conversion summed over clients, fp64-class targets only (k_conv_col_sum); io.items = polynomials per client
+// ModDown conversion summed over clients (k_conv_col_sum), one instance per arithmetic class of the targets;
+// io.items = polynomials per client
+template <int LOG_H, int N_IN>
+static void launch_conv_col_sum_n(const ConvIo &io, const ConvIo &iof, uint32_t tiles, const NttTables &T, const DevConv &cv,
+                                  hipStream_t s) {
+    if (io.nsel) k_conv_col_sum<LOG_H, N_IN, false, DevConv><<<dim3(io.items * tiles * io.nsel), NTT_THREADS, 0, s>>>(io, T, cv);
+    if (iof.nsel) k_conv_col_sum<LOG_H, N_IN, true, DevConv><<<dim3(iof.items * tiles * iof.nsel), NTT_THREADS, 0, s>>>(iof, T, cv);
+}
 template <int LOG_H>
 static void launch_conv_col_sum_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, hipStream_t s) {
     const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
-    ConvIo io = io0;
-    io.target_mask = 0;
-    for (uint32_t j = 0; j < cv.n_out; ++j)
-        if (T.h_fp_of[cv.dst_id[j]]) io.target_mask |= 1ull << j;
+    ConvIo io = io0, iof = io0;
+    io.target_mask = iof.target_mask = 0;
+    for (uint32_t j = 0; j < cv.n_out; ++j) (T.h_fp_of[cv.dst_id[j]] ? iof.target_mask : io.target_mask) |= 1ull << j;
     io.nsel = (uint32_t)__builtin_popcountll(io.target_mask);
-    if (!io.nsel) return;
-    const dim3 grid(io.items * tiles * io.nsel);
+    iof.nsel = (uint32_t)__builtin_popcountll(iof.target_mask);
     switch (cv.n_in) {
-        case 1: k_conv_col_sum<LOG_H, 1, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 2: k_conv_col_sum<LOG_H, 2, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 3: k_conv_col_sum<LOG_H, 3, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 4: k_conv_col_sum<LOG_H, 4, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 5: k_conv_col_sum<LOG_H, 5, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 6: k_conv_col_sum<LOG_H, 6, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 7: k_conv_col_sum<LOG_H, 7, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
-        case 8: k_conv_col_sum<LOG_H, 8, DevConv><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); break;
+        case 1: launch_conv_col_sum_n<LOG_H, 1>(io, iof, tiles, T, cv, s); break;
+        case 2: launch_conv_col_sum_n<LOG_H, 2>(io, iof, tiles, T, cv, s); break;
+        case 3: launch_conv_col_sum_n<LOG_H, 3>(io, iof, tiles, T, cv, s); break;
+        case 4: launch_conv_col_sum_n<LOG_H, 4>(io, iof, tiles, T, cv, s); break;
+        case 5: launch_conv_col_sum_n<LOG_H, 5>(io, iof, tiles, T, cv, s); break;
+        case 6: launch_conv_col_sum_n<LOG_H, 6>(io, iof, tiles, T, cv, s); break;
+        case 7: launch_conv_col_sum_n<LOG_H, 7>(io, iof, tiles, T, cv, s); break;
+        case 8: launch_conv_col_sum_n<LOG_H, 8>(io, iof, tiles, T, cv, s); break;
         default: throw std::invalid_argument("base conversion fan-in unsupported");
     }
 }
@@ -1523,17 +1528,16 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
     // fill the register file of a CU, so the hardware time-slices them instead of co-scheduling.
     const uint32_t max_items = group * std::min(knobs_.chunk, n_ct);
     const size_t w_coef = (size_t)max_items * nl * n, w_dig = (size_t)max_items * nparts * ext * n;
-    const size_t w_pc = (size_t)max_items * 2 * K * n, w_conv = (size_t)max_items * 2 * nl * n;
+    const size_t w_pc = (size_t)max_items * 2 * K * n;
     const size_t w_til = (size_t)max_items * 2 * n_intq * n;
     const size_t w_csum = (size_t)std::min(knobs_.chunk, n_ct) * 2 * nl * n;  // conversions summed over a group's clients
-    u64 *ws = workspace(w_coef + w_dig + w_pc + w_conv + w_til + w_csum);
+    u64 *ws = workspace(w_coef + w_dig + w_pc + w_til + w_csum);
     hipStream_t main = stream_;
     for (uint32_t b0 = 0; b0 < n_ct; b0 += knobs_.chunk) {
         const uint32_t cnt = std::min(knobs_.chunk, n_ct - b0);
         for (uint32_t g0 = 0; g0 < n_clients; g0 += group) {
             const uint32_t gc = std::min(group, n_clients - g0), items = gc * cnt;
-            u64 *coef = ws, *dig = coef + w_coef, *pc = dig + w_dig, *conv = pc + w_pc, *til = conv + w_conv,
-                *convsum = til + w_til;
+            u64 *coef = ws, *dig = coef + w_coef, *pc = dig + w_dig, *til = pc + w_pc, *convsum = til + w_til;
             const u64 *ct0 = cts + ((size_t)g0 * n_ct + b0) * ct_words;  // client g0, index b0
             const u64 *c1 = ct0 + (size_t)nl * n, *evk0 = evks + (size_t)g0 * evk_words;
             const size_t ct_cstride = (size_t)n_ct * ct_words;
@@ -1568,10 +1572,6 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
                 cs.n_clients = gc;
                 cs.in_cstride = (size_t)cnt * 2 * K * n;
                 launch_conv_col_sum(cs, tabs_, cv, main);
-                if (n_intq) {
-                    ConvIo ci{pc, conv, (size_t)K * n, (size_t)nl * n, 2 * items, 0, 0};
-                    launch_conv_col(ci, tabs_, cv, lanes(), 0, 1u);
-                }
             }
             if (n_intq) {  // integer-class Q limbs: accumulators through a compact til
                 InnerArgs aq = ia;
@@ -1582,13 +1582,14 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
                 else launch_row3_inner_int_k<2, false>(aq, tabs_, nparts, ps_.L, nullptr, K, main);
             }
             MK_HIP(hipGetLastError());
-            if (n_intq) {  // q_0: forward row pass of the ModDown conversion + tail + sum over the group's clients
-                SumArgs sa{conv, til, ct0, out + (size_t)b0 * ct_words, pinv, pinv + nl,
-                           (size_t)cnt * 2 * nl * n, (size_t)cnt * 2 * n_intq * n, ct_cstride, ct_words,
-                           gc, nl, n_intq, 2 * cnt, 0, 0, g0 != 0 ? 1u : 0u};
-                sa.til_compact = 1;
-                if (wide_rows) launch_row3_tail_sum<3>(sa, tabs_, main, 1u);
-                else launch_row_tail_sum<4>(sa, tabs_, true, main, 1u);
+            if (n_intq) {  // q_0: row pass of the summed conversion, tail, sum over the group's clients
+                TailOnceArgs ta{convsum, til, ct0, out + (size_t)b0 * ct_words, pinv, pinv + nl,
+                                (size_t)cnt * 2 * n_intq * n, ct_cstride, ct_words, gc, nl, 2 * cnt, intq_mask, n_intq,
+                                g0 != 0 ? 1u : 0u};
+                const uint32_t tiles = (1u << tabs_.log_r1) / (wide_rows ? RowT<3>::ROWS : RowT<2>::ROWS);
+                const dim3 grid(tiles * n_intq * 2 * cnt);
+                if (wide_rows) k_row3_tail_once<3><<<grid, NTT_THREADS, 0, main>>>(ta, tabs_);
+                else k_row3_tail_once<2><<<grid, NTT_THREADS, 0, main>>>(ta, tabs_);
             }
             QSumArgs qa{dig, convsum, ct0, evk0, out + (size_t)b0 * ct_words, pq, ct_cstride, ct_words, evk_words, ct_words,
                         gc, cnt, nl, ext, D, ps_.alpha, fp_mask, (uint32_t)__builtin_popcountll(fp_mask), g0 != 0 ? 1u : 0u};

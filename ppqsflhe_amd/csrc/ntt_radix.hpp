@@ -524,7 +524,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
 // for residue -- each client's conversion is still computed on its own (the approximate conversion is NOT additive in
 // its input; only what follows it is linear).  n - 1 of the n forward transforms per (index, component, limb) disappear.
 // Sources: the K P-limbs of every client as packed 30-bit halves (integer class).
-template <int LOG_H, int N_IN, typename CONV>
+template <int LOG_H, int N_IN, bool FP, typename CONV>
 __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_sum(ConvIo io, NttTables T, CONV cv) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
@@ -544,16 +544,22 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_sum(ConvIo io, NttT
     const uint32_t item = grp / tiles, tile = grp % tiles;
     const uint32_t id = cv.dst_id[jt];
     const LimbConst lc = T.limb[id];
-    if (!lc.fp) return;  // never: the host selects the fp64-class targets
+    if ((lc.fp != 0) != FP) return;  // never: the host selects the targets of this instance's class
     const int c = threadIdx.x % S, j = threadIdx.x / S;
     const u64 *src0 = io.in + (size_t)item * io.in_stride + tile * S + c;
     u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jt] * n + tile * S + c;
     uint32_t h0[N_IN], h1[N_IN];
 #pragma unroll
     for (int i = 0; i < N_IN; ++i) split30(cv.hat[i * cv.n_out + jt], h0[i], h1[i]);
+    // running sums: exact doubles below 0.51 q + 4 q (fp64 class) or lazy integers below 4 q (integer class, q < 2^60)
     double sum[H];
+    u64 isum[H];
 #pragma unroll
-    for (int k = 0; k < H; ++k) sum[k] = 0.0;
+    for (int k = 0; k < H; ++k) {
+        sum[k] = 0.0;
+        isum[k] = 0;
+    }
+    const u64 q4 = lc.q2 + lc.q2;
 #pragma unroll 1
     for (uint32_t cl = 0; cl < io.n_clients; ++cl) {
         const u64 *src = src0 + (size_t)cl * io.in_cstride;
@@ -582,14 +588,14 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_sum(ConvIo io, NttT
                 }
                 v = reduce_cols4(acc, lc);
             }
-            // running sum kept below 0.51 q + 4 q: exact doubles
-            sum[k] = fp_reduce(sum[k] + (double)v, lc.qd, lc.qinv);
+            if (FP) sum[k] = fp_reduce(sum[k] + (double)v, lc.qd, lc.qinv);
+            else isum[k] = csub(isum[k] + (N_IN <= 4 ? v : v), q4);  // < 4q + 4q < 2^63, back below 4q
         }
     }
     u64 x[H];
 #pragma unroll
-    for (int k = 0; k < H; ++k) x[k] = dbits(sum[k]);
-    col_forward_finish<LOG_H, true>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
+    for (int k = 0; k < H; ++k) x[k] = FP ? dbits(sum[k]) : isum[k];  // integer: < 4q, the first stage accepts < 8q
+    col_forward_finish<LOG_H, FP>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
 }
 
 // ApproxModDown tail folded into the copy-out of the forward row pass:
@@ -1547,6 +1553,112 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, N
         r1v.y = fp_to_canonical(acc1[i].y, q, qinv);
         st_stream2(reinterpret_cast<ulong2 *>(t0) + e, r0);
         st_stream2(reinterpret_cast<ulong2 *>(t1) + e, r1v);
+    }
+}
+
+// Integer-class Q limb (q_0) of the merged n-client flow: forward row pass of the ModDown conversion SUMMED over the
+// clients (k_conv_col_sum<.., false>: one transform per group instead of one per client), then
+//   out = ( sum_c ctilde_c - conv_sum ) * P^-1 + sum_c c0_c   (component 0; without the c0 term on component 1)
+// with the clients' key-switch accumulators ctilde_c read from the compact til of k_row3_inner_int.  Ring arithmetic mod
+// q throughout, so the residues are those of the per-client chain.  Three-round geometry: 256- and 512-point rows.
+struct TailOnceArgs {
+    const u64 *conv;   // [poly][nl][N] column-passed summed conversions (lazy < 8q)
+    const u64 *til;    // [client][poly][nsel][N] canonical accumulators of this launch's slots
+    const u64 *cts;    // client c, ciphertext i at cts + c * ct_cstride + i * ct_stride: [2][nl][N]
+    u64 *out;          // [poly][nl][N]
+    const u64 *pinv, *pinv_sh;
+    size_t til_cstride, ct_cstride, ct_stride;
+    uint32_t n_clients, nl, n_polys;
+    unsigned long long slot_mask;
+    uint32_t nsel;
+    uint32_t init_from_out;  // continue a running sum held in `out` (client groups)
+};
+template <int LOGC>
+__global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_once(TailOnceArgs a, NttTables T) {
+    using TL = RowT<LOGC>;
+    constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
+    __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
+    Row3Ctx c;
+    c.lds = lds;
+    c.twa = lds + TL::WORDS;
+    c.twa_sh = c.twa + TL::TWA;
+    c.twb = c.twa_sh + TL::TWA;
+    c.twb_sh = c.twb + TL::TWB;
+    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
+    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
+    uint32_t grp, poly;
+    if (groups % 8 == 0) {
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / a.n_polys) * 8 + xcd;
+        poly = qidx % a.n_polys;
+    } else {
+        grp = blockIdx.x / a.n_polys;
+        poly = blockIdx.x % a.n_polys;
+    }
+    const uint32_t rank = grp / tiles, sl = nth_set_bit(a.slot_mask, rank);  // Q limb: slot == limb id
+    const LimbConst lc = T.limb[sl];
+    const uint32_t row0 = (grp % tiles) * S;
+    c.g = threadIdx.x / TPR;
+    c.t = threadIdx.x % TPR;
+    const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
+    row3_stage_twiddles<LOGC>(c, tw, tw_sh, r1 + row0);
+    u64 wc[7], wpc[7];
+    row3_load_c_twiddles<LOGC>(tw, tw_sh, r1 + row0 + c.g, c.t, wc, wpc);
+    const size_t tile_off = (size_t)row0 * R;
+    u64 x[8];
+    {
+        const u64 *src = a.conv + ((size_t)poly * a.nl + sl) * n + tile_off + (size_t)c.g * R + c.t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + TPR * k);
+    }
+    __syncthreads();  // twiddles staged
+    row3_forward<false, LOGC>(x, c, wc, wpc, lc);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 8 * c.t + k)] = canon8(x[k], lc.q, lc.q2);
+    wave_lds_sync();
+    const u64 pi = a.pinv[sl], pi_sh = a.pinv_sh[sl];
+    const bool with_c0 = (poly & 1) == 0;
+    u64 *dst = a.out + ((size_t)poly * a.nl + sl) * n + tile_off;
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+        const int e = row3_pair<LOGC>(c.g, c.t, i);
+        const int xx = (2 * e) % R;
+        // sums of canonical residues (< 2^60): reduced every 8 terms, so they never pass 9 * 2^60 < 2^64
+        u64 tx = 0, ty = 0, zx = 0, zy = 0;
+        for (uint32_t cl = 0; cl < a.n_clients; ++cl) {
+            const ulong2 tt = ld_stream2(reinterpret_cast<const ulong2 *>(
+                                             a.til + (size_t)cl * a.til_cstride + ((size_t)poly * a.nsel + rank) * n + tile_off) + e);
+            tx += tt.x;
+            ty += tt.y;
+            if (with_c0) {
+                const ulong2 zz = ld_stream2(reinterpret_cast<const ulong2 *>(
+                                                 a.cts + (size_t)cl * a.ct_cstride + (size_t)(poly >> 1) * a.ct_stride +
+                                                 (size_t)sl * n + tile_off) + e);
+                zx += zz.x;
+                zy += zz.y;
+            }
+            if ((cl & 7) == 7) {
+                tx = reduce_word(tx, lc);
+                ty = reduce_word(ty, lc);
+                zx = reduce_word(zx, lc);
+                zy = reduce_word(zy, lc);
+            }
+        }
+        tx = reduce_word(tx, lc);
+        ty = reduce_word(ty, lc);
+        ulong2 v;
+        v.x = shoup_mul(sub_mod(tx, lds[TL::at(c.g, xx)], lc.q), pi, pi_sh, lc.q);
+        v.y = shoup_mul(sub_mod(ty, lds[TL::at(c.g, xx + 1)], lc.q), pi, pi_sh, lc.q);
+        if (with_c0) {
+            v.x = add_mod(v.x, reduce_word(zx, lc), lc.q);
+            v.y = add_mod(v.y, reduce_word(zy, lc), lc.q);
+        }
+        if (a.init_from_out) {
+            const ulong2 o = reinterpret_cast<const ulong2 *>(dst)[e];
+            v.x = add_mod(v.x, o.x, lc.q);
+            v.y = add_mod(v.y, o.y, lc.q);
+        }
+        reinterpret_cast<ulong2 *>(dst)[e] = v;
     }
 }
 

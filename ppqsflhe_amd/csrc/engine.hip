@@ -1048,34 +1048,72 @@ void Engine::mult_const(u64 *ct, uint32_t n_ct, uint32_t nl, const std::vector<u
     MK_HIP(hipGetLastError());
 }
 
+template <int LOG_H>
+static void launch_switch_col(const u64 *last, u64 *out, const NttTables &T, uint32_t n_targets, uint32_t items, u64 q_last,
+                              hipStream_t s) {
+    unsigned long long mi = 0, mf = 0;
+    for (uint32_t i = 0; i < n_targets; ++i) (T.h_fp_of[i] ? mf : mi) |= 1ull << i;
+    const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
+    const uint32_t ni = (uint32_t)__builtin_popcountll(mi), nf = (uint32_t)__builtin_popcountll(mf);
+    if (ni) k_switch_col<LOG_H, false><<<dim3(tiles, ni, items), NTT_THREADS, 0, s>>>(last, out, T, n_targets, q_last, mi);
+    if (nf) k_switch_col<LOG_H, true><<<dim3(tiles, nf, items), NTT_THREADS, 0, s>>>(last, out, T, n_targets, q_last, mf);
+}
+
 void Engine::rescale(const u64 *in, u64 *out, uint32_t n_ct, uint32_t nl, const std::vector<u64> *factors) {
     need_device();
     check_nl(nl);
     if (nl < 2) throw std::invalid_argument("rescale needs at least 2 limbs");
     if (!n_ct) return;
     const uint32_t n = ps_.n, last = nl - 1, items = 2 * n_ct;
-    // constants c_i = q_last^-1 (* EvalMult constant) mod q_i
-    std::vector<u64> c(2 * last);
-    for (uint32_t i = 0; i < last; ++i) {
-        u64 v = ps_.q_inv_mod(last, i);
-        if (factors) v = h_mulmod(v, (*factors)[i], ps_.moduli[i]);
-        c[i] = v;
-        c[last + i] = h_shoup(v, ps_.moduli[i]);
+    // constants c_i = q_last^-1 (* EvalMult constant) mod q_i, cached on the device per (level, constant): no host
+    // synchronisation inside a server step
+    std::string key = "resc_" + std::to_string(nl);
+    if (factors)
+        for (uint32_t i = 0; i < last; ++i) key += "_" + std::to_string((*factors)[i]);
+    const u64 *d_c = nullptr;
+    {
+        auto it = vec_cache_.find(key);
+        if (it != vec_cache_.end()) {
+            d_c = it->second;
+        } else {
+            std::vector<u64> c(2 * last);
+            for (uint32_t i = 0; i < last; ++i) {
+                u64 v = ps_.q_inv_mod(last, i);
+                if (factors) v = h_mulmod(v, (*factors)[i], ps_.moduli[i]);
+                c[i] = v;
+                c[last + i] = h_shoup(v, ps_.moduli[i]);
+            }
+            if (vec_cache_.size() > 4096) throw std::runtime_error("too many distinct rescale constants cached");
+            d_c = limb_vector(key, c);
+        }
     }
     const size_t w_last = (size_t)items * n, w_tmp = (size_t)items * last * n;
-    u64 *ws = workspace(w_last + w_tmp + 2 * last);
-    u64 *d_last = ws, *d_tmp = ws + w_last, *d_c = d_tmp + w_tmp;
-    MK_HIP(hipMemcpyAsync(d_c, c.data(), c.size() * sizeof(u64), hipMemcpyHostToDevice, stream_));
-    MK_HIP(hipStreamSynchronize(stream_));
+    u64 *ws = workspace(w_last + w_tmp);
+    u64 *d_last = ws, *d_tmp = ws + w_last;
     // 1. dropped limb -> COEFFICIENT format
     NttIo io{in, d_last, (size_t)nl * n, (size_t)n, last, 0, last, 1, nl};
     ntt_passes(io, tabs_, items, true, nullptr, nullptr, lanes());
-    // 2. centred switch of modulus into every remaining limb, 3. back to EVALUATION
+    const int col_h = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2);
+    if (col_h >= 2 && row_tail_supported(tabs_)) {
+        // 2. centred switch of modulus fused into the forward column pass of every remaining limb; 3. row pass with
+        // 4. (c_i - tmp_i) * q_last^-1 [* constant] in its copy-out (the ModDown tail with til = the input ciphertext)
+        switch (col_h) {
+            case 4: launch_switch_col<4>(d_last, d_tmp, tabs_, last, items, ps_.moduli[last], stream_); break;
+            case 3: launch_switch_col<3>(d_last, d_tmp, tabs_, last, items, ps_.moduli[last], stream_); break;
+            default: launch_switch_col<2>(d_last, d_tmp, tabs_, last, items, ps_.moduli[last], stream_); break;
+        }
+        MK_HIP(hipGetLastError());
+        NttIo row{d_tmp, out, (size_t)last * n, (size_t)last * n, 0, 0, 0, last, last};
+        TailArgs tail{in, nullptr, d_c, d_c + last, 0, nl, 1, 0u};
+        launch_row<false>(row, tabs_, items, tail, lanes());
+        MK_HIP(hipGetLastError());
+        return;
+    }
+    // ring sizes without the radix kernels: the four steps as separate kernels
     EwGeom g{n, nl, ps_.L};
     k_switch_modulus<<<ew_grid(n, last, items), EW_THREADS, 0, stream_>>>(d_last, d_tmp, g, d_limb_, ps_.moduli[last]);
     MK_HIP(hipGetLastError());
     ntt_launch(d_tmp, items, last, last, false, nullptr, nullptr);
-    // 4. (c_i - tmp_i) * q_last^-1 [* constant]
     k_sub_mul<<<ew_grid(n, last, items), EW_THREADS, 0, stream_>>>(in, d_tmp, out, g, d_limb_, d_c, d_c + last);
     MK_HIP(hipGetLastError());
 }

@@ -598,6 +598,35 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_sum(ConvIo io, NttT
     col_forward_finish<LOG_H, FP>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
 }
 
+// DropLastElementAndScale, first half fused: NativeVectorT::SwitchModulus of the dropped limb (COEFFICIENT format,
+// canonical; centred lift: v > floor(q_last / 2) is negative) into a remaining limb + the forward column pass of that
+// limb -- the switched polynomial never goes to HBM in coefficient form.  last: [items][N]; out: [items][nl-1][N]
+// column-passed; grid (column tile, target limb, item).  The row pass + (c - tmp) * q_last^-1 tail follow in k_ntt_row_r.
+template <int LOG_H, bool FP>
+__global__ __launch_bounds__(NTT_THREADS) void k_switch_col(const u64 *last, u64 *out, NttTables T, uint32_t n_targets,
+                                                            u64 q_last, unsigned long long target_mask) {
+    using TL = ColTile<LOG_H>;
+    constexpr int H = TL::H, S = TL::S;
+    __shared__ u64 lds[TL::WORDS];
+    const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2;
+    const uint32_t sl = nth_set_bit(target_mask, blockIdx.y), item = blockIdx.z;  // remaining Q limb: slot == limb id
+    const LimbConst lc = T.limb[sl];
+    if ((lc.fp != 0) != FP) return;  // never: the host selects the targets of this instance's class
+    const int c = threadIdx.x % S, j = threadIdx.x / S;
+    const u64 *src = last + (size_t)item * n + blockIdx.x * S + c;
+    u64 *dst = out + ((size_t)item * n_targets + sl) * n + blockIdx.x * S + c;
+    const u64 half = q_last >> 1, ql_mod = reduce_word(q_last, lc);
+    u64 x[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        const u64 v = ld_pass(src + (size_t)(j + H * k) * r2);
+        const u64 a = reduce_word(v, lc);
+        const u64 r = v > half ? sub_mod(a, ql_mod, lc.q) : a;
+        x[k] = FP ? dbits(u52_to_double(r)) : r;  // canonical: inside the first round's range for both classes
+    }
+    col_forward_finish<LOG_H, FP>(x, lds, T.tw + (size_t)sl * n, T.tw_sh + (size_t)sl * n, lc, j, c, dst, r2);
+}
+
 // ApproxModDown tail folded into the copy-out of the forward row pass:
 //   out = (ctilde_Q - conv) * P^-1  (+ c0 on component 0)
 struct TailArgs {

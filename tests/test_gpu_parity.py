@@ -353,7 +353,12 @@ def test_reencrypt_accumulate(ctxs, name, nl):
                                          # and two full pairs, a lower level (nl < L)
                                          ("c3", 12, 4, 1), ("c3", 12, 5, 1), ("c3", 11, 2, 2), ("c3", 12, 1, 1),
                                          # N = 2^17: 512-point rows, three-round fused sum / inner-product kernels
-                                         ("n17", 4, 3, 2), ("n17", 3, 2, 1)])
+                                         ("n17", 4, 3, 2), ("n17", 3, 2, 1),
+                                         # merged n-client flow: more clients than one group (8 + 1: the running sum
+                                         # continues from `out`), more indices than one workspace chunk (16 + 3), one
+                                         # client, a level with a single digit and with a partial last digit
+                                         ("ref", 4, 9, 2), ("ref", 4, 3, 19), ("ref", 2, 2, 2), ("ref", 3, 1, 1),
+                                         ("c3", 9, 2, 1), ("c3", 4, 3, 1), ("c3", 2, 2, 1)])
 def test_reencrypt_sum(ctxs, name, nl, C, B):
     # sum over clients of ReEncrypt(ct_c, evk_c) in one call == EvalAdd chain of the individual re-encryptions
     g, o = ctxs(name)

@@ -932,12 +932,13 @@ static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevCo
 // io.items = polynomials per client
 template <int LOG_H, int N_IN>
 static void launch_conv_col_sum_n(const ConvIo &io, const ConvIo &iof, uint32_t tiles, const NttTables &T, const DevConv &cv,
-                                  hipStream_t s) {
-    if (io.nsel) k_conv_col_sum<LOG_H, N_IN, false, DevConv><<<dim3(io.items * tiles * io.nsel), NTT_THREADS, 0, s>>>(io, T, cv);
+                                  hipStream_t s, hipStream_t s_int) {
+    // the integer-class instance (one target, q_0: a few hundred long-running workgroups) beside the fp64 one
+    if (io.nsel) k_conv_col_sum<LOG_H, N_IN, false, DevConv><<<dim3(io.items * tiles * io.nsel), NTT_THREADS, 0, s_int>>>(io, T, cv);
     if (iof.nsel) k_conv_col_sum<LOG_H, N_IN, true, DevConv><<<dim3(iof.items * tiles * iof.nsel), NTT_THREADS, 0, s>>>(iof, T, cv);
 }
 template <int LOG_H>
-static void launch_conv_col_sum_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, hipStream_t s) {
+static void launch_conv_col_sum_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, hipStream_t s, hipStream_t s_int) {
     const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
     ConvIo io = io0, iof = io0;
     io.target_mask = iof.target_mask = 0;
@@ -945,21 +946,21 @@ static void launch_conv_col_sum_h(const ConvIo &io0, const NttTables &T, const D
     io.nsel = (uint32_t)__builtin_popcountll(io.target_mask);
     iof.nsel = (uint32_t)__builtin_popcountll(iof.target_mask);
     switch (cv.n_in) {
-        case 1: launch_conv_col_sum_n<LOG_H, 1>(io, iof, tiles, T, cv, s); break;
-        case 2: launch_conv_col_sum_n<LOG_H, 2>(io, iof, tiles, T, cv, s); break;
-        case 3: launch_conv_col_sum_n<LOG_H, 3>(io, iof, tiles, T, cv, s); break;
-        case 4: launch_conv_col_sum_n<LOG_H, 4>(io, iof, tiles, T, cv, s); break;
-        case 5: launch_conv_col_sum_n<LOG_H, 5>(io, iof, tiles, T, cv, s); break;
-        case 6: launch_conv_col_sum_n<LOG_H, 6>(io, iof, tiles, T, cv, s); break;
-        case 7: launch_conv_col_sum_n<LOG_H, 7>(io, iof, tiles, T, cv, s); break;
-        case 8: launch_conv_col_sum_n<LOG_H, 8>(io, iof, tiles, T, cv, s); break;
+        case 1: launch_conv_col_sum_n<LOG_H, 1>(io, iof, tiles, T, cv, s, s_int); break;
+        case 2: launch_conv_col_sum_n<LOG_H, 2>(io, iof, tiles, T, cv, s, s_int); break;
+        case 3: launch_conv_col_sum_n<LOG_H, 3>(io, iof, tiles, T, cv, s, s_int); break;
+        case 4: launch_conv_col_sum_n<LOG_H, 4>(io, iof, tiles, T, cv, s, s_int); break;
+        case 5: launch_conv_col_sum_n<LOG_H, 5>(io, iof, tiles, T, cv, s, s_int); break;
+        case 6: launch_conv_col_sum_n<LOG_H, 6>(io, iof, tiles, T, cv, s, s_int); break;
+        case 7: launch_conv_col_sum_n<LOG_H, 7>(io, iof, tiles, T, cv, s, s_int); break;
+        case 8: launch_conv_col_sum_n<LOG_H, 8>(io, iof, tiles, T, cv, s, s_int); break;
         default: throw std::invalid_argument("base conversion fan-in unsupported");
     }
 }
-static void launch_conv_col_sum(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s) {
+static void launch_conv_col_sum(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s, hipStream_t s_int) {
     switch (fast_log_h(T.log_r1, 1u << T.log_r2)) {
-        case 4: launch_conv_col_sum_h<4>(io, T, cv, s); break;
-        case 3: launch_conv_col_sum_h<3>(io, T, cv, s); break;
+        case 4: launch_conv_col_sum_h<4>(io, T, cv, s, s_int); break;
+        case 3: launch_conv_col_sum_h<3>(io, T, cv, s, s_int); break;
         default: throw std::logic_error("summed conversion needs 64- or 256-point columns");
     }
     MK_HIP(hipGetLastError());
@@ -1609,7 +1610,16 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
                 ConvIo cs{pc, convsum, (size_t)K * n, (size_t)nl * n, 2 * cnt, 0, 0};
                 cs.n_clients = gc;
                 cs.in_cstride = (size_t)cnt * 2 * K * n;
-                launch_conv_col_sum(cs, tabs_, cv, main);
+                const bool fork = n_intq != 0 && side_stream_ != nullptr && !knobs_.one_lane;
+                if (fork) {
+                    MK_HIP(hipEventRecord(ev_fork_, main));
+                    MK_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
+                }
+                launch_conv_col_sum(cs, tabs_, cv, main, fork ? side_stream_ : main);
+                if (fork) {
+                    MK_HIP(hipEventRecord(ev_join_, side_stream_));
+                    MK_HIP(hipStreamWaitEvent(main, ev_join_, 0));
+                }
             }
             if (n_intq) {  // integer-class Q limbs: accumulators through a compact til
                 InnerArgs aq = ia;

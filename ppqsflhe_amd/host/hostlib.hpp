@@ -664,18 +664,24 @@ inline Ciphertext gather_agg_inputs(const std::vector<AggItem> &items, size_t n_
     return first;
 }
 // EvalMult(sum, 1/n) (aggregateEncryptedWeights.cpp:83,92,107) on d_sum [B][2][nl][N] and the output document
-inline void finish_aggregate(Session &s, const std::vector<AggItem> &items, uint64_t *d_sum, const Ciphertext &first,
-                             size_t n_clients, Json &outputJson) {
+// the aggregate as it sits in HBM after EvalMult(., 1/n): B ciphertexts [B][2][meta.nl][N] (+ the header fields every
+// one of them carries)
+struct AggResult {
+    uint64_t *d_out = nullptr;
+    Ciphertext meta;
+};
+
+inline AggResult scale_aggregate(Session &s, size_t B, uint64_t *d_sum, const Ciphertext &first, size_t n_clients) {
     const uint32_t N = s.N(), nl = first.nl;
-    const size_t B = items.size();
-    Ciphertext res;
-    uint64_t *d_out = d_sum;
+    AggResult r;
+    Ciphertext &res = r.meta;
+    r.d_out = d_sum;
     const double operand = 1.0 / (double)n_clients;  // 0.5 for the reference's two clients
     if (first.noise_deg == 2) {
         // EvalMult(ct, double): rescale first (ModReduceInternalInPlace), then the integer constant
         if (nl < 2) throw std::runtime_error("ciphertext has no limb left to rescale");
-        d_out = s.alloc<uint64_t>(B * (size_t)2 * (nl - 1) * N);
-        Session::check(mkckks_rescale_mult_const_batch(s.ctx(), d_sum, d_out, (uint32_t)B, nl, operand));
+        r.d_out = s.alloc<uint64_t>(B * (size_t)2 * (nl - 1) * N);
+        Session::check(mkckks_rescale_mult_const_batch(s.ctx(), d_sum, r.d_out, (uint32_t)B, nl, operand));
         res.nl = nl - 1;
         res.level = first.level + 1;
         res.scale = first.scale / (double)s.moduli()[nl - 1] * s.sf(res.level, false);
@@ -688,17 +694,31 @@ inline void finish_aggregate(Session &s, const std::vector<AggItem> &items, uint
         res.noise_deg = first.noise_deg + 1;
     }
     res.slots = first.slots;
-    const size_t owords = (size_t)2 * res.nl * N;
+    return r;
+}
+
+// download B ciphertexts [B][2][meta.nl][N] and put them where `items` say in the envelope
+inline void store_agg_items(Session &s, const std::vector<AggItem> &items, const uint64_t *d_cts, Ciphertext meta,
+                            Json &outputJson) {
+    const uint32_t N = s.N();
+    const size_t B = items.size(), owords = (size_t)2 * meta.nl * N;
     std::vector<uint64_t> out(B * owords);
-    s.to_host(out.data(), d_out, out.size());
+    s.to_host(out.data(), d_cts, out.size());
     for (size_t b = 0; b < B; ++b) {
-        res.data.assign(out.begin() + b * owords, out.begin() + (b + 1) * owords);
+        meta.data.assign(out.begin() + b * owords, out.begin() + (b + 1) * owords);
         Json &lay = outputJson["weights_summary"].a[items[b].out_layer];
-        std::string b64 = encode_ct(res, N);
+        std::string b64 = encode_ct(meta, N);
         if (items[b].field == 0) lay["mean"] = std::move(b64);
         else if (items[b].field == 1) lay["std_dev"] = std::move(b64);
         else lay["values"].a[items[b].idx] = Json(std::move(b64));
     }
+}
+
+inline AggResult finish_aggregate(Session &s, const std::vector<AggItem> &items, uint64_t *d_sum, const Ciphertext &first,
+                                  size_t n_clients, Json &outputJson) {
+    AggResult r = scale_aggregate(s, items.size(), d_sum, first, n_clients);
+    store_agg_items(s, items, r.d_out, r.meta, outputJson);
+    return r;
 }
 
 }  // namespace mkh

@@ -5,25 +5,40 @@
 //   aggregateEncryptedWeights <cc> <enc_target> <tmp_...> <out>
 // each of which re-loads the CryptoContext, re-parses base64-in-JSON and moves every ciphertext through the host.  Here:
 //   serverRound <cc_path> <output_aggfile> <rekey_1|-> <encfile_1> [<rekey_2|-> <encfile_2> ...]
+//               [--back <rekey_back_1> <output_encfile_1> [<rekey_back_2> <output_encfile_2> ...]]
 // "-" as the re-encryption key marks a client whose ciphertexts already are in the target domain (the reference's
 // client 2).  All ciphertexts go to HBM once; the re-encryption of every re-keyed client and the sum over clients is ONE
 // mkckks_reencrypt_sum_batch call (cc->ReEncrypt x n at changeCipherDomain.cpp:74 + the EvalAdd chain of
 // aggregateEncryptedWeights.cpp:82), then EvalMult(., 1/n) (:83).  The output file is bit-identical to the one the
 // per-client programs produce (PRE is deterministic; tests/test_cli_hosts.py).
+// After --back: the n-1 re-encryptions of the aggregate into the other clients' key domains (the reference's
+// s_changeCipherDomain_c2_c1, server_fns.sh:76-80: changeCipherDomain <cc> <rekey_back_c> <aggfile> <out_c>) -- the
+// aggregate stays in HBM, one mkckks_reencrypt_batch per key; each file equals changeCipherDomain run on <output_aggfile>.
 #include "hostlib.hpp"
 using namespace mkh;
 
 int main(int argc, char *argv[]) {
-    if (argc < 5 || (argc - 3) % 2 != 0) {
+    int n_args = argc;
+    for (int i = 3; i < argc; ++i)
+        if (std::string(argv[i]) == "--back") {
+            n_args = i;
+            break;
+        }
+    const int n_back_args = argc - n_args - (n_args < argc ? 1 : 0);
+    if (n_args < 5 || (n_args - 3) % 2 != 0 || n_back_args % 2 != 0 || (n_args < argc && n_back_args == 0)) {
         std::cerr << "Usage: " << argv[0] << " <cc_path> <output_aggfile> <rekey_1|-> <encfile_1> [<rekey_2|-> <encfile_2> ...]"
-                  << std::endl;
+                  << " [--back <rekey_back_1> <output_encfile_1> ...]" << std::endl;
         return 1;
     }
     const std::string cc_path = argv[1], output_file = argv[2];
-    std::vector<std::string> rekey_paths, enc_paths;
-    for (int i = 3; i + 1 < argc; i += 2) {
+    std::vector<std::string> rekey_paths, enc_paths, back_keys, back_outs;
+    for (int i = 3; i + 1 < n_args; i += 2) {
         rekey_paths.push_back(argv[i]);
         enc_paths.push_back(argv[i + 1]);
+    }
+    for (int i = n_args + 1; i + 1 < argc; i += 2) {
+        back_keys.push_back(argv[i]);
+        back_outs.push_back(argv[i + 1]);
     }
     CcFile cc;
     try {
@@ -69,6 +84,8 @@ int main(int argc, char *argv[]) {
         raw_blobs() = binary;
         Json outputJson;
         const std::vector<AggItem> items = build_agg_items(files, outputJson);
+        AggResult agg;
+        uint64_t *d_back = nullptr, *d_back_evk = nullptr;
         if (!items.empty()) {
             std::vector<uint64_t> flat;  // [client in `order`][ct][2][nl][N]
             const Ciphertext first = gather_agg_inputs(items, n_clients, s, flat);
@@ -92,9 +109,27 @@ int main(int argc, char *argv[]) {
                 Session::check(mkckks_eval_sum_batch(s.ctx(), d_terms, d_sum, (uint32_t)(n_plain + (n_pre ? 1 : 0)),
                                                      (uint32_t)B, nl));
             }
-            finish_aggregate(s, items, d_sum, first, n_clients, outputJson);
+            agg = finish_aggregate(s, items, d_sum, first, n_clients, outputJson);
         }
         write_envelope(outputJson, output_file, binary);
+        for (size_t k = 0; k < back_keys.size(); ++k) {
+            std::vector<uint64_t> evk;
+            if (!load_eval_key(s, back_keys[k], evk)) {
+                std::cerr << "[round] ERROR: Failed to load ReKey from " << back_keys[k] << std::endl;
+                return 1;
+            }
+            Json backJson = outputJson;  // layer / shape carried over; blobs replaced below
+            if (!items.empty()) {
+                const size_t words = items.size() * (size_t)2 * agg.meta.nl * N;
+                if (!d_back) d_back = s.alloc<uint64_t>(words);
+                if (!d_back_evk) d_back_evk = s.alloc<uint64_t>(evk_words);
+                Session::check(mkckks_upload(s.ctx(), d_back_evk, evk.data(), evk_words * 8));
+                Session::check(mkckks_reencrypt_batch(s.ctx(), agg.d_out, d_back_evk, d_back, (uint32_t)items.size(), agg.meta.nl));
+                store_agg_items(s, items, d_back, agg.meta, backJson);
+            }
+            write_envelope(backJson, back_outs[k], binary);
+            std::cout << "[round] aggregate re-encrypted with " << back_keys[k] << " -> " << back_outs[k] << "\n";
+        }
     } catch (const std::exception &e) {
         std::cerr << "[round] ERROR: " << e.what() << std::endl;
         return 1;

@@ -381,6 +381,54 @@ def test_server_round_n_clients_equals_the_per_client_programs(tmp_path, n):
 
 
 @pytest.mark.gpu
+def test_server_round_sends_the_aggregate_back_to_every_client(tmp_path):
+    """The last leg of the round (orchestration/server_fns.sh:76-80, run.sh:42): the aggregate, which lives in the target
+    client's key domain at one limb fewer, is re-encrypted into each other client's domain.  `serverRound ... --back`
+    does it while the aggregate is still in HBM; every file must equal changeCipherDomain run on the aggregate file,
+    and every client must decrypt the mean with its OWN secret key."""
+    n = 3
+    cc = _small_cc(tmp_path)
+    rng = np.random.default_rng(77)
+
+    def ok(r):
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r
+
+    vals = [[("dense", rng.uniform(-0.3, 0.3, 300)), ("bias", rng.uniform(-0.3, 0.3, 4))] for _ in range(n)]
+    for c in range(n):
+        ok(run("keyGen", cc, tmp_path / f"pk{c}", tmp_path / f"sk{c}"))
+        ok(run("encryptModelWeights", cc, tmp_path / f"pk{c}", _weights(tmp_path, f"w{c}.json", vals[c]), tmp_path / f"enc{c}.json"))
+    target = n - 1
+    args, back = [], []
+    for c in range(n - 1):
+        ok(run("REkeyGen", cc, tmp_path / f"sk{c}", tmp_path / f"pk{target}", tmp_path / f"rk{c}"))
+        ok(run("REkeyGen", cc, tmp_path / f"sk{target}", tmp_path / f"pk{c}", tmp_path / f"rkback{c}"))
+        args += [tmp_path / f"rk{c}", tmp_path / f"enc{c}.json"]
+        back += [tmp_path / f"rkback{c}", tmp_path / f"agg_for{c}.json"]
+    r = ok(run("serverRound", cc, tmp_path / "agg.json", "-", tmp_path / f"enc{target}.json", *args, "--back", *back))
+    assert r.stdout.count("[round] aggregate re-encrypted with") == n - 1
+    mean = [np.mean([np.asarray(vals[c][li][1]) for c in range(n)], axis=0) for li in range(2)]
+    for c in range(n - 1):
+        ok(run("changeCipherDomain", cc, tmp_path / f"rkback{c}", tmp_path / "agg.json", tmp_path / f"ref_for{c}.json"))
+        assert json.load(open(tmp_path / f"agg_for{c}.json")) == json.load(open(tmp_path / f"ref_for{c}.json"))
+        ok(run("decryptModelWeights", cc, tmp_path / f"sk{c}", tmp_path / f"agg_for{c}.json", tmp_path / f"dec{c}.json"))
+        dec = json.load(open(tmp_path / f"dec{c}.json"))["weights_summary"]
+        for li in range(2):
+            assert np.abs(np.array(dec[li]["values"]) - mean[li]).max() < 2.0 ** -24, (c, li)
+    # the wrong key must not decrypt it (sanity of the test itself)
+    ok(run("decryptModelWeights", cc, tmp_path / f"sk{target}", tmp_path / "agg_for0.json", tmp_path / "wrong.json"))
+    wrong = json.load(open(tmp_path / "wrong.json"))["weights_summary"]
+    assert not (np.abs(np.array(wrong[0]["values"], dtype=float) - mean[0]).max() < 1.0)
+    # usage: --back with nothing after it, or an odd count
+    r = run("serverRound", cc, tmp_path / "x.json", "-", tmp_path / "enc0.json", "--back")
+    assert r.returncode == 1 and "Usage:" in r.stderr
+    r = run("serverRound", cc, tmp_path / "x.json", "-", tmp_path / "enc0.json", "--back", tmp_path / "rkback0")
+    assert r.returncode == 1 and "Usage:" in r.stderr
+    r = run("serverRound", cc, tmp_path / "x.json", "-", tmp_path / f"enc{target}.json", "--back", tmp_path / "nope", tmp_path / "y.json")
+    assert r.returncode == 1 and "[round] ERROR: Failed to load ReKey" in r.stderr
+
+
+@pytest.mark.gpu
 def test_aggregate_emits_one_entry_per_matching_pair(tmp_path):
     """aggregateEncryptedWeights.cpp:68-72,115: the reference's nested loops emit an output entry for EVERY (w2, w1) pair
     with equal layer and shape -- duplicate layer names included -- and none for unmatched entries."""

@@ -20,6 +20,7 @@
 #include "sampler_kernels.hpp"
 
 #include <cmath>
+#include <type_traits>
 #include <cstdlib>
 #include <cstring>
 
@@ -484,6 +485,7 @@ Knobs Knobs::from_env() {
         if (v == 2 || v == 3 || v == 4) k.qsum_geom = v;
     }
     k.generic_ntt = env_flag("MKCKKS_GENERIC_NTT", k.generic_ntt);
+    k.no_pm = env_flag("MKCKKS_NO_PM", k.no_pm);
     k.no_fp64 = env_flag("MKCKKS_NO_FP64", k.no_fp64);
     k.fuse_inner = env_flag("MKCKKS_FUSE_INNER", k.fuse_inner);
     k.fuse_inner_int = env_flag("MKCKKS_FUSE_INNER_INT", k.fuse_inner_int);
@@ -520,6 +522,19 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device), knobs
         fp_of_[i] = (uint8_t)ps_.limb[i].fp;
         tabs_.has_fp |= ps_.limb[i].fp;
     }
+    // integer limbs of the form 2^k - c (the 60-bit q_0 and P limbs OpenFHE generates): pseudo-Mersenne butterflies, if
+    // EVERY integer limb of the context qualifies and both passes run on the radix kernels (the generic LDS-stage kernels
+    // are Shoup-only) -- one integer arithmetic per context, chosen at launch (AR_PM / AR_INT kernel instances).
+    // MKCKKS_NO_PM=1 keeps Shoup's.
+    bool all_pm = radix_both && !knobs_.no_pm;
+    for (uint32_t i = 0; i < D; ++i)
+        if (!ps_.limb[i].fp && !pm_eligible(ps_.moduli[i])) all_pm = false;
+    tabs_.int_pm = all_pm ? 1u : 0u;
+    for (uint32_t i = 0; i < D; ++i) {
+        const bool pm = all_pm && !ps_.limb[i].fp;
+        ps_.limb[i].pm = pm ? 1u : 0u;
+        ps_.limb[i].pm_c = pm ? (uint32_t)(((u64)1 << ps_.limb[i].k) - ps_.moduli[i]) : 0u;
+    }
     tabs_.h_fp_of = fp_of_.data();
     MK_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));  // second client lane of reencrypt_sum
     MK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
@@ -540,13 +555,19 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device), knobs
             std::memcpy(&wsh[k], &wq, 8);
         }
     };
+    auto as_pm = [&](uint32_t i) {  // Shoup companion -> w * 2^32 mod q
+        const u64 q = ps_.moduli[i];
+        for (uint32_t k = 0; k < n; ++k) wsh[k] = (u64)(((u128)w[k] << 32) % q);
+    };
     for (uint32_t i = 0; i < D; ++i) {
         ps_.twiddles(i, false, w, wsh);
         if (ps_.limb[i].fp) as_fp(i);
+        if (ps_.limb[i].pm) as_pm(i);
         MK_HIP(hipMemcpy(d_tw_ + (size_t)i * n, w.data(), n * sizeof(u64), hipMemcpyHostToDevice));
         MK_HIP(hipMemcpy(d_tw_sh_ + (size_t)i * n, wsh.data(), n * sizeof(u64), hipMemcpyHostToDevice));
         ps_.twiddles(i, true, w, wsh);
         if (ps_.limb[i].fp) as_fp(i);
+        if (ps_.limb[i].pm) as_pm(i);
         MK_HIP(hipMemcpy(d_itw_ + (size_t)i * n, w.data(), n * sizeof(u64), hipMemcpyHostToDevice));
         MK_HIP(hipMemcpy(d_itw_sh_ + (size_t)i * n, wsh.data(), n * sizeof(u64), hipMemcpyHostToDevice));
     }
@@ -777,6 +798,13 @@ static void launch_two_classes(const Lanes &ln, bool has_int, bool has_fp, FInt 
 }
 
 // slots of `io` whose limb runs on the fp64 (want_fp) or the integer instance; fp_of: per-limb-id class (host copy)
+// the integer instance of a radix kernel in the context's integer arithmetic: f(integral_constant<int, AR_PM | AR_INT>)
+template <typename F>
+static void with_int_arith(const NttTables &T, F &&f) {
+    if (T.int_pm) f(std::integral_constant<int, AR_PM>{});
+    else f(std::integral_constant<int, AR_INT>{});
+}
+
 static unsigned long long class_mask(const NttIo &io, const unsigned char *fp_of, uint32_t L, bool want_fp) {
     unsigned long long m = 0;
     for (uint32_t b = 0; b < io.nslots; ++b) {
@@ -799,17 +827,17 @@ static void launch_col(const NttIo &io0, const NttTables &T, uint32_t n_polys, c
     switch (fast_log_h(T.log_r1, r2)) {
         case 4:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { k_ntt_col_r<4, INV, false><<<dim3(r2 / 16, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); },
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_col_r<4, INV, decltype(ar)::value><<<dim3(r2 / 16, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); }); },
                 [&](hipStream_t s) { k_ntt_col_r<4, INV, true><<<dim3(r2 / 16, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack); });
             break;
         case 3:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { k_ntt_col_r<3, INV, false><<<dim3(r2 / 32, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); },
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_col_r<3, INV, decltype(ar)::value><<<dim3(r2 / 32, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); }); },
                 [&](hipStream_t s) { k_ntt_col_r<3, INV, true><<<dim3(r2 / 32, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack); });
             break;
         case 2:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { k_ntt_col_r<2, INV, false><<<dim3(r2 / 64, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); },
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_col_r<2, INV, decltype(ar)::value><<<dim3(r2 / 64, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); }); },
                 [&](hipStream_t s) { k_ntt_col_r<2, INV, true><<<dim3(r2 / 64, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack); });
             break;
         default:
@@ -836,22 +864,22 @@ static void launch_row(const NttIo &io0, const NttTables &T, uint32_t n_polys, c
     switch (fast_row(T.log_r2, r1)) {
         case 9:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { k_ntt_row3<INV, false><<<dim3((r1 / 4) * items), NTT_THREADS, 0, s>>>(io, T, tail); },
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_row3<INV, decltype(ar)::value><<<dim3((r1 / 4) * items), NTT_THREADS, 0, s>>>(io, T, tail); }); },
                 [&](hipStream_t s) { k_ntt_row3<INV, true><<<dim3((r1 / 4) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
             break;
         case 4:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { k_ntt_row_r<4, INV, false><<<dim3((r1 / 16) * items), NTT_THREADS, 0, s>>>(io, T, tail); },
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_row_r<4, INV, decltype(ar)::value><<<dim3((r1 / 16) * items), NTT_THREADS, 0, s>>>(io, T, tail); }); },
                 [&](hipStream_t s) { k_ntt_row_r<4, INV, true><<<dim3((r1 / 16) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
             break;
         case 3:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { k_ntt_row_r<3, INV, false><<<dim3((r1 / 32) * items), NTT_THREADS, 0, s>>>(io, T, tail); },
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_row_r<3, INV, decltype(ar)::value><<<dim3((r1 / 32) * items), NTT_THREADS, 0, s>>>(io, T, tail); }); },
                 [&](hipStream_t s) { k_ntt_row_r<3, INV, true><<<dim3((r1 / 32) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
             break;
         case 2:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { k_ntt_row_r<2, INV, false><<<dim3((r1 / 64) * items), NTT_THREADS, 0, s>>>(io, T, tail); },
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_row_r<2, INV, decltype(ar)::value><<<dim3((r1 / 64) * items), NTT_THREADS, 0, s>>>(io, T, tail); }); },
                 [&](hipStream_t s) { k_ntt_row_r<2, INV, true><<<dim3((r1 / 64) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
             break;
         default: {
@@ -888,7 +916,7 @@ template <int LOG_H, int N_IN, int SRCMODE>
 static void launch_conv_col_n(const ConvIo &io, const ConvIo &iof, const dim3 &grid, const dim3 &gridf, const NttTables &T,
                               const DevConv &cv, const Lanes &ln) {
     launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
-        [&](hipStream_t s) { k_conv_col<LOG_H, N_IN, false, DevConv, SRCMODE><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); },
+        [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_conv_col<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); }); },
         [&](hipStream_t s) { k_conv_col<LOG_H, N_IN, true, DevConv, SRCMODE><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
 }
 template <int LOG_H, int N_IN>
@@ -934,7 +962,7 @@ template <int LOG_H, int N_IN>
 static void launch_conv_col_sum_n(const ConvIo &io, const ConvIo &iof, uint32_t tiles, const NttTables &T, const DevConv &cv,
                                   hipStream_t s, hipStream_t s_int) {
     // the integer-class instance (one target, q_0: a few hundred long-running workgroups) beside the fp64 one
-    if (io.nsel) k_conv_col_sum<LOG_H, N_IN, false, DevConv><<<dim3(io.items * tiles * io.nsel), NTT_THREADS, 0, s_int>>>(io, T, cv);
+    if (io.nsel) with_int_arith(T, [&](auto ar) { k_conv_col_sum<LOG_H, N_IN, decltype(ar)::value, DevConv><<<dim3(io.items * tiles * io.nsel), NTT_THREADS, 0, s_int>>>(io, T, cv); });
     if (iof.nsel) k_conv_col_sum<LOG_H, N_IN, true, DevConv><<<dim3(iof.items * tiles * iof.nsel), NTT_THREADS, 0, s>>>(iof, T, cv);
 }
 template <int LOG_H>
@@ -1056,7 +1084,7 @@ static void launch_switch_col(const u64 *last, u64 *out, const NttTables &T, uin
     for (uint32_t i = 0; i < n_targets; ++i) (T.h_fp_of[i] ? mf : mi) |= 1ull << i;
     const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
     const uint32_t ni = (uint32_t)__builtin_popcountll(mi), nf = (uint32_t)__builtin_popcountll(mf);
-    if (ni) k_switch_col<LOG_H, false><<<dim3(tiles, ni, items), NTT_THREADS, 0, s>>>(last, out, T, n_targets, q_last, mi);
+    if (ni) with_int_arith(T, [&](auto ar) { k_switch_col<LOG_H, decltype(ar)::value><<<dim3(tiles, ni, items), NTT_THREADS, 0, s>>>(last, out, T, n_targets, q_last, mi); });
     if (nf) k_switch_col<LOG_H, true><<<dim3(tiles, nf, items), NTT_THREADS, 0, s>>>(last, out, T, n_targets, q_last, mf);
 }
 
@@ -1352,12 +1380,12 @@ static void launch_row3_inner_int_k(const InnerArgs &a, const NttTables &T, uint
     if (!a.nsel) return;
     const dim3 grid(((1u << T.log_r1) / RowT<LOGC>::ROWS) * a.nsel * a.items);
     switch (nparts) {
-        case 1: k_row3_inner_int<1, LOGC, INVP><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); break;
-        case 2: k_row3_inner_int<2, LOGC, INVP><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); break;
-        case 3: k_row3_inner_int<3, LOGC, INVP><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); break;
-        case 4: k_row3_inner_int<4, LOGC, INVP><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); break;
-        case 5: k_row3_inner_int<5, LOGC, INVP><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); break;
-        case 6: k_row3_inner_int<6, LOGC, INVP><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); break;
+        case 1: with_int_arith(T, [&](auto ar) { k_row3_inner_int<1, LOGC, INVP, decltype(ar)::value><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); }); break;
+        case 2: with_int_arith(T, [&](auto ar) { k_row3_inner_int<2, LOGC, INVP, decltype(ar)::value><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); }); break;
+        case 3: with_int_arith(T, [&](auto ar) { k_row3_inner_int<3, LOGC, INVP, decltype(ar)::value><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); }); break;
+        case 4: with_int_arith(T, [&](auto ar) { k_row3_inner_int<4, LOGC, INVP, decltype(ar)::value><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); }); break;
+        case 5: with_int_arith(T, [&](auto ar) { k_row3_inner_int<5, LOGC, INVP, decltype(ar)::value><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); }); break;
+        case 6: with_int_arith(T, [&](auto ar) { k_row3_inner_int<6, LOGC, INVP, decltype(ar)::value><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); }); break;
         default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
     }
 }
@@ -1457,7 +1485,7 @@ static void launch_row3_tail_sum(SumArgs a, const NttTables &T, hipStream_t s, u
     for (uint32_t i = 0; i < a.nl; ++i) (T.h_fp_of[i] ? af.slot_mask : ai.slot_mask) |= 1ull << i;
     ai.nsel = (uint32_t)__builtin_popcountll(ai.slot_mask);
     af.nsel = (uint32_t)__builtin_popcountll(af.slot_mask);
-    if (ai.nsel && (classes & 1)) k_row3_tail_sum<false, LOGC><<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s>>>(ai, T);
+    if (ai.nsel && (classes & 1)) with_int_arith(T, [&](auto ar) { k_row3_tail_sum<decltype(ar)::value, LOGC><<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s>>>(ai, T); });
     if (af.nsel && (classes & 2)) k_row3_tail_sum<true, LOGC><<<dim3(tiles * af.nsel * a.n_polys), NTT_THREADS, 0, s>>>(af, T);
 }
 
@@ -1475,11 +1503,11 @@ static void launch_row_tail_sum(SumArgs a, const NttTables &T, bool pair, hipStr
     // two clients per workgroup iteration (shared twiddle fetches, two dependency chains): the default; 2 waves per
     // SIMD either way (212 VGPRs, no spills; measured equal to 3 waves, faster than 4)
     if (pair && LOG_H == 4) {
-        if (ai.nsel) k_row_tail_sum2<LOG_H, false><<<gi, NTT_THREADS, 0, s>>>(ai, T);
+        if (ai.nsel) with_int_arith(T, [&](auto ar) { k_row_tail_sum2<LOG_H, decltype(ar)::value><<<gi, NTT_THREADS, 0, s>>>(ai, T); });
         if (af.nsel) k_row_tail_sum2<LOG_H, true><<<gf, NTT_THREADS, 0, s>>>(af, T);
     } else {
         if (a.til_compact) throw std::logic_error("compact accumulators need the paired sum kernel");
-        if (ai.nsel) k_row_tail_sum<LOG_H, false, 2><<<gi, NTT_THREADS, 0, s>>>(ai, T);
+        if (ai.nsel) with_int_arith(T, [&](auto ar) { k_row_tail_sum<LOG_H, decltype(ar)::value, 2><<<gi, NTT_THREADS, 0, s>>>(ai, T); });
         if (af.nsel) k_row_tail_sum<LOG_H, true, 2><<<gf, NTT_THREADS, 0, s>>>(af, T);
     }
 }
@@ -1636,8 +1664,8 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
                                 g0 != 0 ? 1u : 0u};
                 const uint32_t tiles = (1u << tabs_.log_r1) / (wide_rows ? RowT<3>::ROWS : RowT<2>::ROWS);
                 const dim3 grid(tiles * n_intq * 2 * cnt);
-                if (wide_rows) k_row3_tail_once<3><<<grid, NTT_THREADS, 0, main>>>(ta, tabs_);
-                else k_row3_tail_once<2><<<grid, NTT_THREADS, 0, main>>>(ta, tabs_);
+                if (wide_rows) with_int_arith(tabs_, [&](auto ar) { k_row3_tail_once<3, decltype(ar)::value><<<grid, NTT_THREADS, 0, main>>>(ta, tabs_); });
+                else with_int_arith(tabs_, [&](auto ar) { k_row3_tail_once<2, decltype(ar)::value><<<grid, NTT_THREADS, 0, main>>>(ta, tabs_); });
             }
             QSumArgs qa{dig, convsum, ct0, evk0, out + (size_t)b0 * ct_words, pq, ct_cstride, ct_words, evk_words, ct_words,
                         gc, cnt, nl, ext, D, ps_.alpha, fp_mask, (uint32_t)__builtin_popcountll(fp_mask), g0 != 0 ? 1u : 0u};

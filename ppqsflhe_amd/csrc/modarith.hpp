@@ -50,8 +50,22 @@ struct LimbConst {
     double ninv_d;    // (double) N^-1 mod q
     double ninv_qd;   // ninv_d / q
     uint32_t fp;      // 1: this limb's NTT tables hold doubles (w, w/q) and its inter-pass data are doubles
+    // pseudo-Mersenne path (integer limbs with q = 2^k - c, c <= 2^(k-34) -- every 60-bit prime OpenFHE's generator
+    // picks is one: it walks down from 2^60 in steps of 2N): the NTT tables' companions hold w * 2^32 mod q and the
+    // butterflies reduce by folding at bit k (pm_lazy / pm_fold below) instead of Shoup's quotient estimate
+    uint32_t pm;
+    uint32_t pm_c;    // c = 2^k - q
     uint32_t pad_;
 };
+
+// whether q qualifies for the pseudo-Mersenne butterflies (host side; the engine additionally wants an integer limb)
+MK_HD bool pm_eligible(u64 q) {
+    uint32_t k = 0;
+    while (k < 64 && (q >> k)) ++k;
+    if (k < 40 || k > 60) return false;
+    const u64 c = ((u64)1 << k) - q;
+    return c <= ((u64)1 << (k - 34));
+}
 
 MK_HD u64 mulhi64(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -93,6 +107,50 @@ MK_HD u64 shoup_lazy(u64 a, u64 w, u64 wp, u64 q) {
 }
 // canonical result in [0, q)
 MK_HD u64 shoup_mul(u64 a, u64 w, u64 wp, u64 q) { return csub(shoup_lazy(a, w, wp, q), q); }
+
+// ---- pseudo-Mersenne limbs: q = 2^k - c, c <= 2^(k-34), U := 2^k --------------------------------------------------
+// gfx950 issues v_mad_u64_u32 at the rate of a 32-bit add (tools/ubench_intmul.hip), so what counts is the NUMBER of
+// instructions.  Shoup's product is 3 multiplies for the quotient's high word + 2 x 3 for the two low products plus
+// their glue (~15 instructions); with 2^k = c (mod q) a product is reduced by folding its bits above k back in with one
+// small multiply: 5 v_mad_u64_u32 + 6 of glue.
+struct PmK {           // wave-uniform shifts / masks / constants of one limb
+    uint32_t c, c2;    // c, 2c
+    uint32_t s_hi, m_hi;  // split of a 96-bit product's upper 64 bits at bit k+1: shift k+1-32, mask 2^(k+1-32) - 1
+    uint32_t s_f, m_f;    // split of a 64-bit word at bit k: shift k-32, mask 2^(k-32) - 1
+    u64 q3;            // 3q >= any pm_lazy result (offset of the butterflies' subtractions)
+};
+MK_HD PmK pm_consts(const LimbConst &L) {
+    PmK p;
+    p.c = L.pm_c;
+    p.c2 = 2 * L.pm_c;
+    p.s_hi = L.k + 1 - 32;
+    p.m_hi = (1u << p.s_hi) - 1u;
+    p.s_f = L.k - 32;
+    p.m_f = (1u << p.s_f) - 1u;
+    p.q3 = 3 * L.q;
+    return p;
+}
+// x (any 64-bit word) -> x mod q in [0, U + 2^30):  (x mod 2^k) + (x >> k) c, and (x >> k) c < 2^(64-k) 2^(k-34).
+MK_HD u64 pm_fold(u64 x, const PmK &P) {
+    const uint32_t xh = (uint32_t)(x >> 32);
+    const u64 lo = ((u64)(xh & P.m_f) << 32) | (uint32_t)x;
+    return (u64)(xh >> P.s_f) * P.c + lo;
+}
+// a * w mod q, lazy, for a < 8U = 2^(k+3), w < q and the companion wx = w * 2^32 mod q:
+//   S = a_lo w + a_hi wx  = a w (mod q),  S < 2^32 U + 2^(k-29) U <= 1.5 * 2^32 U   (96 bits: z : low word of y1)
+//   S = hi 2^(k+1) + lo,  hi < 1.5 * 2^31,  2^(k+1) = 2c (mod q)  ->  lo + hi 2c < 2U + 0.375U.
+// Result in [0, 2.375U).  y1 cannot wrap: a_hi < 2^31 and wx_lo < 2^32.
+MK_HD u64 pm_lazy(u64 a, u64 w, u64 wx, const PmK &P) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
+    const u64 y0 = (u64)a0 * (uint32_t)w;
+    u64 z = (u64)a0 * (uint32_t)(w >> 32) + (y0 >> 32);
+    const u64 y1 = (u64)a1 * (uint32_t)wx + (uint32_t)y0;
+    z += (u64)a1 * (uint32_t)(wx >> 32);
+    z += y1 >> 32;
+    const uint32_t hi = (uint32_t)(z >> P.s_hi);
+    const u64 lo = ((u64)((uint32_t)z & P.m_hi) << 32) | (uint32_t)y1;
+    return (u64)hi * P.c2 + lo;
+}
 
 // Barrett reduction of a 128-bit x = hi:lo with x < 2^(k+62) (k = bitlen q) to [0,q).
 // qhat = mulhi64(x >> (k-2), mu), mu = floor(2^(62+k)/q): qhat in {Q-2,Q-1,Q}.

@@ -41,7 +41,10 @@ struct NttTables {
     uint32_t L;  // #Q limbs at full level (P limbs start at id L)
     uint32_t has_fp;  // some limbs run on the fp64 kernel instances (host launches both instances then)
     const unsigned char *h_fp_of;  // HOST pointer (never read on the device): per limb id, 1 = fp64 instance
+    uint32_t int_pm;  // HOST decision: the integer limbs run on the AR_PM instances (all of them qualify), else AR_INT
 };
+// arithmetic of a radix-kernel instance (template parameter AR; AR_INT / AR_FP keep the values of the old bool)
+constexpr int AR_INT = 0, AR_FP = 1, AR_PM = 2;
 
 struct NttIo {
     const u64 *in;
@@ -113,6 +116,30 @@ MK_D void gs_butterfly(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 q2) {
     u64 d = x + q2 - y;
     x = csub(s, q2);
     y = shoup_lazy(d, w, wp, q);
+}
+// pseudo-Mersenne butterflies (LimbConst::pm, U = 2^k; bounds of pm_lazy / pm_fold in modarith.hpp).
+// forward, "f": x is folded below U + 2^30 first; with y < 8U: v < 2.375U, x' < 3.376U, y' = u - v + 3q < 4.001U.
+// forward, "n": x < 4.001U as is: x' < 6.376U, y' < 7.001U < 8U = the multiplier's input bound.
+// A round alternates f, n, f, n: its outputs stay below 7.001U < 8q, which is what the integer consumers (canon8, the
+// next round's first stage) are written for.
+MK_D void ct_butterfly_pm_f(u64 &x, u64 &y, u64 w, u64 wx, const PmK &P) {
+    const u64 u = pm_fold(x, P);
+    const u64 v = pm_lazy(y, w, wx, P);
+    x = u + v;
+    y = u - v + P.q3;
+}
+MK_D void ct_butterfly_pm_n(u64 &x, u64 &y, u64 w, u64 wx, const PmK &P) {
+    const u64 v = pm_lazy(y, w, wx, P);
+    const u64 u = x;
+    x = u + v;
+    y = u - v + P.q3;
+}
+// inverse: x, y < 2.375U -> x' = fold(x + y) < 1.001U, d = x - y + 3q < 5.375U, y' = d w < 2.375U
+MK_D void gs_butterfly_pm(u64 &x, u64 &y, u64 w, u64 wx, const PmK &P) {
+    const u64 s = x + y;
+    const u64 d = x - y + P.q3;
+    x = pm_fold(s, P);
+    y = pm_lazy(d, w, wx, P);
 }
 MK_D u64 canon8(u64 v, u64 q, u64 q2) {  // [0,8q) -> [0,q)
     return csub(csub(csub(v, q2 + q2), q2), q);

@@ -11,9 +11,11 @@
 //   inverse (Gentleman-Sande) runs round B then round A with the stages reversed.
 //   Twiddle of in-register stage s, group g (g < 2^s): table[(base_eff << s) + g].
 //
-// Every kernel exists in two arithmetic instances (template parameter FP): integer (Shoup/Harvey lazy butterflies on
-// v_mad_u64_u32) for the 60-bit limbs and fp64 (exact FMA products, see modarith.hpp) for limbs below 1.25 * 2^50;
-// the host launches each instance over the limbs of its class.  512-point rows (N = 2^17) use three rounds of
+// Every kernel exists in three arithmetic instances (template parameter AR): fp64 (AR_FP: exact FMA products, see
+// modarith.hpp) for limbs below 1.25 * 2^50, and for the 60-bit limbs either the pseudo-Mersenne butterflies (AR_PM:
+// q = 2^k - c, reduction by folding at bit k; what OpenFHE's 60-bit primes allow) or Shoup/Harvey lazy butterflies
+// (AR_INT, any modulus); the host launches the fp64 and the integer instance over the limbs of their class, and picks
+// ONE integer arithmetic per context (NttTables::int_pm: every integer limb qualifies for AR_PM).  512-point rows (N = 2^17) use three rounds of
 // radix 8 (k_ntt_row3).  Fused kernels: k_conv_col (approximate base conversion + forward column pass),
 // k_row_inner_fp (forward row pass of the converted digits + eval-key inner product, fp64 limbs), k_row_tail_sum /
 // k_row_tail_sum2 (forward row pass + ModDown tail + sum over clients), and their three-round counterparts
@@ -141,6 +143,38 @@ MK_D void radix_inverse(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], 
     }
 }
 
+// the same rounds with the pseudo-Mersenne butterflies (LimbConst::pm; bounds next to ct_butterfly_pm_f): inputs < 8U,
+// outputs < 7.001U forward; inputs and outputs < 2.375U inverse
+template <int LOG_H>
+MK_D void radix_forward_pm(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], const u64 (&wx)[(1 << LOG_H) - 1],
+                           const PmK &P) {
+    constexpr int H = 1 << LOG_H;
+#pragma unroll
+    for (int s = 0; s < LOG_H; ++s) {
+        const int dist = H >> (s + 1);
+#pragma unroll
+        for (int p = 0; p < H / 2; ++p) {
+            const int g = p / dist, k0 = g * 2 * dist + (p % dist);
+            if (s % 2 == 0) ct_butterfly_pm_f(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wx[(1 << s) - 1 + g], P);
+            else ct_butterfly_pm_n(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wx[(1 << s) - 1 + g], P);
+        }
+    }
+}
+template <int LOG_H>
+MK_D void radix_inverse_pm(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], const u64 (&wx)[(1 << LOG_H) - 1],
+                           const PmK &P) {
+    constexpr int H = 1 << LOG_H;
+#pragma unroll
+    for (int s = LOG_H - 1; s >= 0; --s) {
+        const int dist = H >> (s + 1);
+#pragma unroll
+        for (int p = 0; p < H / 2; ++p) {
+            const int g = p / dist, k0 = g * 2 * dist + (p % dist);
+            gs_butterfly_pm(x[k0], x[k0 + dist], w[(1 << s) - 1 + g], wx[(1 << s) - 1 + g], P);
+        }
+    }
+}
+
 // ---- fp64 rounds (limbs with LimbConst::fp): x[], w[], wq[] hold DOUBLE bit patterns -----------------
 // forward: v = y*w mod q (|v| <= q(0.5 + 1.0001|y|/2^52)); x is re-centred (u = reduce(x), |u| <= 0.51q) on the even
 // stages of a round only; with q < 1.25*2^50 every value stays below 3.1q.  inverse: s = x + y is reduced, d = x - y goes straight into the
@@ -195,16 +229,18 @@ MK_D void radix_inverse_fp(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1
 }
 // dispatch on the arithmetic of the kernel instance (FP is a template parameter of every radix kernel: the two
 // arithmetics get their own register allocation; a launch of one instance skips the limbs of the other class)
-template <int LOG_H, bool FP>
+template <int LOG_H, int AR>
 MK_D void radix_forward_any(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], const u64 (&wp)[(1 << LOG_H) - 1],
                             const LimbConst &lc) {
-    if (FP) radix_forward_fp<LOG_H>(x, w, wp, lc.qd, lc.qinv);
+    if (AR == AR_FP) radix_forward_fp<LOG_H>(x, w, wp, lc.qd, lc.qinv);
+    else if (AR == AR_PM) radix_forward_pm<LOG_H>(x, w, wp, pm_consts(lc));
     else radix_forward<LOG_H>(x, w, wp, lc.q, lc.q2);
 }
-template <int LOG_H, bool FP>
+template <int LOG_H, int AR>
 MK_D void radix_inverse_any(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 1], const u64 (&wp)[(1 << LOG_H) - 1],
                             const LimbConst &lc) {
-    if (FP) radix_inverse_fp<LOG_H>(x, w, wp, lc.qd, lc.qinv);
+    if (AR == AR_FP) radix_inverse_fp<LOG_H>(x, w, wp, lc.qd, lc.qinv);
+    else if (AR == AR_PM) radix_inverse_pm<LOG_H>(x, w, wp, pm_consts(lc));
     else radix_inverse<LOG_H>(x, w, wp, lc.q, lc.q2);
 }
 
@@ -309,14 +345,14 @@ MK_D void stage_twiddles_wave(u64 *ldsw, u64 *ldswp, const u64 *tw, const u64 *t
 
 // Forward column pass, everything after the H input words of this thread (rows j + H k, column c) are
 // in x[]: round A, LDS exchange, round B, store rows H j + k (lazy [0,8q): the row pass finishes).
-template <int LOG_H, bool FP>
+template <int LOG_H, int AR>
 MK_D void col_forward_finish(u64 (&x)[1 << LOG_H], u64 *lds, const u64 *tw, const u64 *tw_sh, const LimbConst &lc,
                              int j, int c, u64 *dst_col, uint32_t r2) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H;
     u64 w[H - 1], wp[H - 1], w2[H - 1], wp2[H - 1];
     load_round_twiddles<LOG_H>(tw, tw_sh, 1u, w, wp);  // same for every column: scalar loads
-    radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+    radix_forward_any<LOG_H, AR>(x, w, wp, lc);
     // second-round twiddles are requested BEFORE the exchange: their L2 latency runs under the barrier wait
     load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w2, wp2);
 #pragma unroll
@@ -324,14 +360,14 @@ MK_D void col_forward_finish(u64 (&x)[1 << LOG_H], u64 *lds, const u64 *tw, cons
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < H; ++k) x[k] = lds[TL::at(j, k, c)];  // row H j + k
-    radix_forward_any<LOG_H, FP>(x, w2, wp2, lc);
+    radix_forward_any<LOG_H, AR>(x, w2, wp2, lc);
 #pragma unroll
     for (int k = 0; k < H; ++k) st_pass(dst_col + (size_t)(H * j + k) * r2, x[k]);  // lazy u64, or doubles on an fp limb
 }
 
 // Column pass over R1 = H*H rows: one workgroup = S = 256/H adjacent columns.  Global accesses are
 // S x 8-B row segments (128 B at H = 16); one LDS exchange between the two rounds.
-template <int LOG_H, bool INV, bool FP>
+template <int LOG_H, bool INV, int AR>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T, const u64 *scale,
                                                            const u64 *scale_sh, int pack) {
     using TL = ColTile<LOG_H>;
@@ -341,7 +377,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
     if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;  // block-uniform
     const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
     const LimbConst lc = T.limb[id];
-    if ((lc.fp != 0) != FP) return;  // never: the host selects the slots of this instance's class
+    if ((lc.fp != 0) != (AR == AR_FP)) return;  // never: the host selects the slots of this instance's class
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2;
     const int c = threadIdx.x % S, j = threadIdx.x / S;
     const u64 *src = io.in + (size_t)poly * io.in_stride + (size_t)(io.in_slot0 + sl) * n + blockIdx.x * S + c;
@@ -352,37 +388,37 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
     if (!INV) {
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = ld_pass(src + (size_t)(j + H * k) * r2);
-        if (FP) {  // canonical residues -> doubles (exact, q < 2^51)
+        if (AR == AR_FP) {  // canonical residues -> doubles (exact, q < 2^51)
 #pragma unroll
             for (int k = 0; k < H; ++k) x[k] = dbits((double)x[k]);
         }
-        col_forward_finish<LOG_H, FP>(x, lds, tw, tw_sh, lc, j, c, dst, r2);
+        col_forward_finish<LOG_H, AR>(x, lds, tw, tw_sh, lc, j, c, dst, r2);
     } else {
         u64 w[H - 1], wp[H - 1];
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = ld_pass(src + (size_t)(H * j + k) * r2);  // from the row pass: doubles on an fp limb
         load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w, wp);
-        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
+        radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(j, k, c)] = x[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(k, j, c)];
         load_round_twiddles<LOG_H>(tw, tw_sh, 1u, w, wp);
-        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
+        radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
         // scale by N^-1 (x folded constant): table entries are (u64, Shoup) or, on an fp limb, (double, double/q)
-        const u64 sc = scale ? scale[id] : (FP ? dbits(lc.ninv_d) : lc.ninv);
-        const u64 sc_sh = scale ? scale_sh[id] : (FP ? dbits(lc.ninv_qd) : lc.ninv_sh);
+        const u64 sc = scale ? scale[id] : ((AR == AR_FP) ? dbits(lc.ninv_d) : lc.ninv);
+        const u64 sc_sh = scale ? scale_sh[id] : ((AR == AR_FP) ? dbits(lc.ninv_qd) : lc.ninv_sh);
 #pragma unroll
         for (int k = 0; k < H; ++k) {
-            if (FP && pack == 2) {
+            if ((AR == AR_FP) && pack == 2) {
                 // canonical residue as a double for k_conv_col's fp64 products: |x| <= 1.33 q -> |s| <= 0.92 q, so one
                 // conditional add lands in [0, q) (the same value fp_to_canonical returns)
                 double sd = fp_mulmod(bitsd(x[k]), bitsd(sc), bitsd(sc_sh), lc.qd);
                 sd = sd < 0.0 ? sd + lc.qd : sd;
                 st_pass(dst + (size_t)(j + H * k) * r2, dbits(sd));
             } else {
-                const u64 v = FP ? fp_to_canonical(fp_mulmod(bitsd(x[k]), bitsd(sc), bitsd(sc_sh), lc.qd), lc.qd, lc.qinv)
+                const u64 v = (AR == AR_FP) ? fp_to_canonical(fp_mulmod(bitsd(x[k]), bitsd(sc), bitsd(sc_sh), lc.qd), lc.qd, lc.qinv)
                                  : shoup_mul(x[k], sc, sc_sh, lc.q);
                 st_pass(dst + (size_t)(j + H * k) * r2, pack ? pack30(v) : v);  // packed halves feed k_conv_col directly
             }
@@ -419,7 +455,7 @@ template <int SRCMODE>
 MK_D constexpr bool src_is_double(int i) {
     return SRCMODE == 1 || (SRCMODE == 2 && i > 0);
 }
-template <int LOG_H, int N_IN, bool FP, typename CONV, int SRCMODE = 0>
+template <int LOG_H, int N_IN, int AR, typename CONV, int SRCMODE = 0>
 __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T, CONV cv) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
@@ -440,7 +476,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
     const uint32_t item = grp / tiles, tile = grp % tiles;
     const uint32_t id = cv.dst_id[jt];
     const LimbConst lc = T.limb[id];
-    if ((lc.fp != 0) != FP) return;  // block-uniform
+    if ((lc.fp != 0) != (AR == AR_FP)) return;  // block-uniform
     const int c = threadIdx.x % S, j = threadIdx.x / S;
     const u64 *src = io.in + (size_t)item * io.in_stride + tile * S + c;
     u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jt] * n + tile * S + c;
@@ -454,7 +490,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
         double hd[N_IN], hq[N_IN];
 #pragma unroll
         for (int i = 0; i < N_IN; ++i) {
-            if (FP && src_is_double<SRCMODE>(i)) {
+            if ((AR == AR_FP) && src_is_double<SRCMODE>(i)) {
                 hd[i] = cv.hat_d[i * cv.n_out + jt];
                 hq[i] = cv.hatq_d[i * cv.n_out + jt];
             } else {
@@ -466,7 +502,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
             u64 p[N_IN];
 #pragma unroll
             for (int i = 0; i < N_IN; ++i) p[i] = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2];
-            if (FP && SRCMODE != 0) {
+            if ((AR == AR_FP) && SRCMODE != 0) {
                 double acc = 0.0;
                 if (SRCMODE == 2) {  // the packed source(s): column accumulation, below 4q < 2^53
                     Cols ia{0, 0, 0};
@@ -494,7 +530,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
                     mac_cols(acc, a0, a1, h0[i], h1[i]);
                 }
                 x[k] = reduce_cols_lazy(acc, lc);  // < 4q: the first butterfly stage accepts < 8q
-                if (FP) x[k] = dbits(fp_reduce((double)x[k], lc.qd, lc.qinv));  // < 4q < 2^53: exact in a double
+                if (AR == AR_FP) x[k] = dbits(fp_reduce((double)x[k], lc.qd, lc.qinv));  // < 4q < 2^53: exact in a double
             }
         }
     } else {
@@ -511,10 +547,10 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
                 mac_cols4(acc, (uint32_t)p, (uint32_t)(p >> 32), h0[i], h1[i]);
             }
             x[k] = reduce_cols4(acc, lc);
-            if (FP) x[k] = dbits(fp_reduce((double)x[k], lc.qd, lc.qinv));
+            if (AR == AR_FP) x[k] = dbits(fp_reduce((double)x[k], lc.qd, lc.qinv));
         }
     }
-    col_forward_finish<LOG_H, FP>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
+    col_forward_finish<LOG_H, AR>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
 }
 
 // ApproxModDown's conversion P -> Q_l for an fp64-class target, SUMMED OVER CLIENTS before the forward transform:
@@ -524,7 +560,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
 // for residue -- each client's conversion is still computed on its own (the approximate conversion is NOT additive in
 // its input; only what follows it is linear).  n - 1 of the n forward transforms per (index, component, limb) disappear.
 // Sources: the K P-limbs of every client as packed 30-bit halves (integer class).
-template <int LOG_H, int N_IN, bool FP, typename CONV>
+template <int LOG_H, int N_IN, int AR, typename CONV>
 __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_sum(ConvIo io, NttTables T, CONV cv) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
@@ -544,7 +580,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_sum(ConvIo io, NttT
     const uint32_t item = grp / tiles, tile = grp % tiles;
     const uint32_t id = cv.dst_id[jt];
     const LimbConst lc = T.limb[id];
-    if ((lc.fp != 0) != FP) return;  // never: the host selects the targets of this instance's class
+    if ((lc.fp != 0) != (AR == AR_FP)) return;  // never: the host selects the targets of this instance's class
     const int c = threadIdx.x % S, j = threadIdx.x / S;
     const u64 *src0 = io.in + (size_t)item * io.in_stride + tile * S + c;
     u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jt] * n + tile * S + c;
@@ -588,21 +624,21 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_sum(ConvIo io, NttT
                 }
                 v = reduce_cols4(acc, lc);
             }
-            if (FP) sum[k] = fp_reduce(sum[k] + (double)v, lc.qd, lc.qinv);
+            if (AR == AR_FP) sum[k] = fp_reduce(sum[k] + (double)v, lc.qd, lc.qinv);
             else isum[k] = csub(isum[k] + (N_IN <= 4 ? v : v), q4);  // < 4q + 4q < 2^63, back below 4q
         }
     }
     u64 x[H];
 #pragma unroll
-    for (int k = 0; k < H; ++k) x[k] = FP ? dbits(sum[k]) : isum[k];  // integer: < 4q, the first stage accepts < 8q
-    col_forward_finish<LOG_H, FP>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
+    for (int k = 0; k < H; ++k) x[k] = (AR == AR_FP) ? dbits(sum[k]) : isum[k];  // integer: < 4q, the first stage accepts < 8q
+    col_forward_finish<LOG_H, AR>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
 }
 
 // DropLastElementAndScale, first half fused: NativeVectorT::SwitchModulus of the dropped limb (COEFFICIENT format,
 // canonical; centred lift: v > floor(q_last / 2) is negative) into a remaining limb + the forward column pass of that
 // limb -- the switched polynomial never goes to HBM in coefficient form.  last: [items][N]; out: [items][nl-1][N]
 // column-passed; grid (column tile, target limb, item).  The row pass + (c - tmp) * q_last^-1 tail follow in k_ntt_row_r.
-template <int LOG_H, bool FP>
+template <int LOG_H, int AR>
 __global__ __launch_bounds__(NTT_THREADS) void k_switch_col(const u64 *last, u64 *out, NttTables T, uint32_t n_targets,
                                                             u64 q_last, unsigned long long target_mask) {
     using TL = ColTile<LOG_H>;
@@ -611,7 +647,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_switch_col(const u64 *last, u64
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2;
     const uint32_t sl = nth_set_bit(target_mask, blockIdx.y), item = blockIdx.z;  // remaining Q limb: slot == limb id
     const LimbConst lc = T.limb[sl];
-    if ((lc.fp != 0) != FP) return;  // never: the host selects the targets of this instance's class
+    if ((lc.fp != 0) != (AR == AR_FP)) return;  // never: the host selects the targets of this instance's class
     const int c = threadIdx.x % S, j = threadIdx.x / S;
     const u64 *src = last + (size_t)item * n + blockIdx.x * S + c;
     u64 *dst = out + ((size_t)item * n_targets + sl) * n + blockIdx.x * S + c;
@@ -622,9 +658,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_switch_col(const u64 *last, u64
         const u64 v = ld_pass(src + (size_t)(j + H * k) * r2);
         const u64 a = reduce_word(v, lc);
         const u64 r = v > half ? sub_mod(a, ql_mod, lc.q) : a;
-        x[k] = FP ? dbits(u52_to_double(r)) : r;  // canonical: inside the first round's range for both classes
+        x[k] = (AR == AR_FP) ? dbits(u52_to_double(r)) : r;  // canonical: inside the first round's range for both classes
     }
-    col_forward_finish<LOG_H, FP>(x, lds, T.tw + (size_t)sl * n, T.tw_sh + (size_t)sl * n, lc, j, c, dst, r2);
+    col_forward_finish<LOG_H, AR>(x, lds, T.tw + (size_t)sl * n, T.tw_sh + (size_t)sl * n, lc, j, c, dst, r2);
 }
 
 // ApproxModDown tail folded into the copy-out of the forward row pass:
@@ -641,7 +677,7 @@ struct TailArgs {
 
 // Row pass over rows of R2 = H*H contiguous words: one workgroup = S consecutive rows (S*R2 contiguous
 // words).  The side that needs per-thread contiguous runs goes through LDS with coalesced 16-B accesses.
-template <int LOG_H, bool INV, bool FP>
+template <int LOG_H, bool INV, int AR>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T, TailArgs tail) {
     using TL = RowTile<LOG_H>;
     using TA = RowTwA<LOG_H>;
@@ -666,7 +702,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
     if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;  // block-uniform
     const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
     const LimbConst lc = T.limb[id];
-    if ((lc.fp != 0) != FP) return;  // block-uniform
+    if ((lc.fp != 0) != (AR == AR_FP)) return;  // block-uniform
     const uint32_t row0 = (grp % tiles) * S;
     const int g = threadIdx.x / H, j = threadIdx.x % H;
     const u64 *src = io.in + ntt_in_offset(io, poly) + (size_t)(io.in_slot0 + sl) * n + (size_t)row0 * R;
@@ -681,7 +717,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);
         wave_lds_sync();
         TA::fetch(twa, twa_sh, g, w, wp);
-        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+        radix_forward_any<LOG_H, AR>(x, w, wp, lc);
         u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
         load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
 #pragma unroll
@@ -689,10 +725,10 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
-        radix_forward_any<LOG_H, FP>(x, w2, wp2, lc);
+        radix_forward_any<LOG_H, AR>(x, w2, wp2, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k)  // canonical u64, own words only
-            lds[TL::at(g, H * j + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
+            lds[TL::at(g, H * j + k)] = (AR == AR_FP) ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
         wave_lds_sync();
         if (!tail.enabled) {
             for (int i = 0; i < PAIRS; ++i) {
@@ -742,18 +778,18 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
-        if (FP) {  // canonical input -> doubles
+        if (AR == AR_FP) {  // canonical input -> doubles
 #pragma unroll
             for (int k = 0; k < H; ++k) x[k] = dbits((double)x[k]);
         }
-        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
+        radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = x[k];
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, j + H * k)];
         TA::fetch(twa, twa_sh, g, w, wp);
-        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
+        radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) st_pass(dst + (size_t)g * R + j + H * k, x[k]);  // lazy [0,2q) (doubles on an fp limb): the column pass scales
     }
@@ -778,7 +814,7 @@ struct SumArgs {
     uint32_t init_from_out;  // continue a running sum: the accumulators start from `out` instead of zero
     uint32_t til_compact = 0;  // til holds only this launch's slots: [client][poly][nsel][N], slot index = rank in slot_mask
 };
-template <int LOG_H, bool FP, int WAVES>
+template <int LOG_H, int AR, int WAVES>
 __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, NttTables T) {
     using TL = RowTile<LOG_H>;
     using TA = RowTwA<LOG_H>;
@@ -798,7 +834,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, 
     }
     const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);  // Q limb: slot == limb id
     const LimbConst lc = T.limb[sl];
-    if ((lc.fp != 0) != FP) return;
+    if ((lc.fp != 0) != (AR == AR_FP)) return;
     const uint32_t row0 = (grp % tiles) * S;
     const int g = threadIdx.x / H, j = threadIdx.x % H;
     const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
@@ -821,17 +857,17 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, 
         u64 w[H - 1], wp[H - 1];
         wave_lds_sync();  // twiddles staged (first client) / previous client's copy-out finished reading LDS
         TA::fetch(twa, twa_sh, g, w, wp);
-        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+        radix_forward_any<LOG_H, AR>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
         load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w, wp);
-        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+        radix_forward_any<LOG_H, AR>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k)
-            lds[TL::at(g, H * j + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
+            lds[TL::at(g, H * j + k)] = (AR == AR_FP) ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
         if (c + 1 < a.n_clients) {
             const u64 *nxt = src0 + (size_t)(c + 1) * a.conv_cstride;
 #pragma unroll
@@ -867,7 +903,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, 
 // so every twiddle fetched (LDS broadcast in round A, per-thread global loads in round B) feeds two butterflies and
 // the two independent dependency chains cover each other's LDS / memory latency at 2 waves per SIMD.  An odd client
 // count runs its last iteration with the second slot masked (its loads alias the first slot's client).
-template <int LOG_H, bool FP>
+template <int LOG_H, int AR>
 __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, NttTables T) {
     using TL = RowTile<LOG_H>;
     using TA = RowTwA<LOG_H>;
@@ -887,7 +923,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
     }
     const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);  // Q limb: slot == limb id
     const LimbConst lc = T.limb[sl];
-    if ((lc.fp != 0) != FP) return;
+    if ((lc.fp != 0) != (AR == AR_FP)) return;
     const uint32_t row0 = (grp % tiles) * S;
     const int g = threadIdx.x / H, j = threadIdx.x % H;
     const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
@@ -919,8 +955,8 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
             u64 w[H - 1], wp[H - 1];
             wave_lds_sync();  // twiddles staged (first pair) / previous pair's tail finished reading LDS
             TA::fetch(twa, twa_sh, g, w, wp);
-            radix_forward_any<LOG_H, FP>(xa, w, wp, lc);
-            radix_forward_any<LOG_H, FP>(xb, w, wp, lc);
+            radix_forward_any<LOG_H, AR>(xa, w, wp, lc);
+            radix_forward_any<LOG_H, AR>(xb, w, wp, lc);
         }
         u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
         load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
@@ -935,12 +971,12 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
             xa[k] = lds[TL::at(g, H * j + k)];
             xb[k] = ldsb[TL::at(g, H * j + k)];
         }
-        radix_forward_any<LOG_H, FP>(xa, w2, wp2, lc);
-        radix_forward_any<LOG_H, FP>(xb, w2, wp2, lc);
+        radix_forward_any<LOG_H, AR>(xa, w2, wp2, lc);
+        radix_forward_any<LOG_H, AR>(xb, w2, wp2, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) {
-            lds[TL::at(g, H * j + k)] = FP ? fp_to_canonical(bitsd(xa[k]), lc.qd, lc.qinv) : canon8(xa[k], lc.q, lc.q2);
-            ldsb[TL::at(g, H * j + k)] = FP ? fp_to_canonical(bitsd(xb[k]), lc.qd, lc.qinv) : canon8(xb[k], lc.q, lc.q2);
+            lds[TL::at(g, H * j + k)] = (AR == AR_FP) ? fp_to_canonical(bitsd(xa[k]), lc.qd, lc.qinv) : canon8(xa[k], lc.q, lc.q2);
+            ldsb[TL::at(g, H * j + k)] = (AR == AR_FP) ? fp_to_canonical(bitsd(xb[k]), lc.qd, lc.qinv) : canon8(xb[k], lc.q, lc.q2);
         }
         if (c + 2 < a.n_clients) {  // next pair's inputs are requested while this pair's tail streams
             const u64 *na = src0 + (size_t)(c + 2) * a.conv_cstride;
@@ -1143,7 +1179,7 @@ struct RowT {
     static MK_D int at(int g, int x) { return g * RS + x + (x >> 3); }
 };
 using Row3 = RowT<3>;
-template <bool INV, bool FP>
+template <bool INV, int AR>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T, TailArgs tail) {
     using TL = Row3;
     constexpr int H = 8, LOG_H = 3, R = TL::R, S = TL::ROWS;
@@ -1164,7 +1200,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T,
     if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;
     const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
     const LimbConst lc = T.limb[id];
-    if ((lc.fp != 0) != FP) return;
+    if ((lc.fp != 0) != (AR == AR_FP)) return;
     const uint32_t row0 = (grp % tiles) * S;
     const int g = threadIdx.x / 64, t = threadIdx.x % 64, p = t / 8, r = t % 8;
     const u64 *src = io.in + (size_t)poly * io.in_stride + (size_t)(io.in_slot0 + sl) * n + (size_t)row0 * R;
@@ -1211,24 +1247,24 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T,
         for (int k = 0; k < H; ++k) x[k] = src[(size_t)g * R + t + 64 * k];  // doubles from the column pass on an fp limb
         __syncthreads();
         fetch_a();
-        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+        radix_forward_any<LOG_H, AR>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, t + 64 * k)] = x[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, 64 * p + 8 * k + r)];
         fetch_b();
-        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+        radix_forward_any<LOG_H, AR>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, 64 * p + 8 * k + r)] = x[k];  // own words
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, 64 * p + 8 * r + k)];
         load_round_twiddles<LOG_H>(tw, tw_sh, base * 64 + 8 * p + r, w, wp);
-        radix_forward_any<LOG_H, FP>(x, w, wp, lc);
+        radix_forward_any<LOG_H, AR>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k)
-            lds[TL::at(g, 64 * p + 8 * r + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
+            lds[TL::at(g, 64 * p + 8 * r + k)] = (AR == AR_FP) ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
         __syncthreads();
         if (!tail.enabled) {
             for (int e = threadIdx.x; e < S * R / 2; e += NTT_THREADS) {
@@ -1273,26 +1309,26 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T,
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, 64 * p + 8 * r + k)];
-        if (FP) {
+        if (AR == AR_FP) {
 #pragma unroll
             for (int k = 0; k < H; ++k) x[k] = dbits((double)x[k]);
         }
         load_round_twiddles<LOG_H>(tw, tw_sh, base * 64 + 8 * p + r, w, wp);
-        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
+        radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, 64 * p + 8 * r + k)] = x[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, 64 * p + 8 * k + r)];
         fetch_b();
-        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
+        radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(g, 64 * p + 8 * k + r)] = x[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, t + 64 * k)];
         fetch_a();
-        radix_inverse_any<LOG_H, FP>(x, w, wp, lc);
+        radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) dst[(size_t)g * R + t + 64 * k] = x[k];  // lazy [0,2q) / doubles: the column pass scales
     }
@@ -1344,7 +1380,7 @@ MK_D void row3_load_c_twiddles(const u64 *tw, const u64 *tw_sh, uint32_t base, i
 }
 // forward transform of this thread's row: x[k] = word t + TPR k on entry; on exit x[k] = word 8 t + k in the lazy
 // range of the arithmetic
-template <bool FP, int LOGC>
+template <int AR, int LOGC>
 MK_D void row3_forward(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], const u64 (&wpc)[7], const LimbConst &lc) {
     using TL = RowT<LOGC>;
     constexpr int S = TL::ROWS, TPR = TL::TPR, C = TL::C;
@@ -1358,7 +1394,7 @@ MK_D void row3_forward(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], const 
             w[(1 << s) - 1 + gg] = c.twa[e];
             wp[(1 << s) - 1 + gg] = c.twa_sh[e];
         }
-    radix_forward_any<3, FP>(x, w, wp, lc);
+    radix_forward_any<3, AR>(x, w, wp, lc);
 #pragma unroll
     for (int k = 0; k < 8; ++k) c.lds[TL::at(c.g, c.t + TPR * k)] = x[k];
     wave_lds_sync();
@@ -1372,20 +1408,20 @@ MK_D void row3_forward(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], const 
             w[(1 << s) - 1 + gg] = c.twb[e];
             wp[(1 << s) - 1 + gg] = c.twb_sh[e];
         }
-    radix_forward_any<3, FP>(x, w, wp, lc);
+    radix_forward_any<3, AR>(x, w, wp, lc);
 #pragma unroll
     for (int k = 0; k < 8; ++k) c.lds[TL::at(c.g, 8 * C * a + C * k + cc)] = x[k];  // own words
     wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = c.lds[TL::at(c.g, 8 * c.t + k)];
     if (LOGC == 3) {
-        radix_forward_any<3, FP>(x, wc, wpc, lc);
+        radix_forward_any<3, AR>(x, wc, wpc, lc);
     } else {  // two radix-4 groups: words 8t..8t+3 and 8t+4..8t+7
         u64 y0[4] = {x[0], x[1], x[2], x[3]}, y1[4] = {x[4], x[5], x[6], x[7]};
         const u64 w0[3] = {wc[0], wc[1], wc[2]}, wp0[3] = {wpc[0], wpc[1], wpc[2]};
         const u64 w1[3] = {wc[3], wc[4], wc[5]}, wp1[3] = {wpc[3], wpc[4], wpc[5]};
-        radix_forward_any<2, FP>(y0, w0, wp0, lc);
-        radix_forward_any<2, FP>(y1, w1, wp1, lc);
+        radix_forward_any<2, AR>(y0, w0, wp0, lc);
+        radix_forward_any<2, AR>(y1, w1, wp1, lc);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             x[k] = y0[k];
@@ -1398,7 +1434,7 @@ template <int LOGC>
 MK_D int row3_pair(int g, int t, int i) { return g * (RowT<LOGC>::R / 2) + t + RowT<LOGC>::TPR * i; }
 
 // ModDown row pass + tail + sum over clients (see k_row_tail_sum) on 512-point rows
-template <bool FP, int LOGC>
+template <int AR, int LOGC>
 __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_sum(SumArgs a, NttTables T) {
     using TL = RowT<LOGC>;
     constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
@@ -1422,7 +1458,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_sum(SumArgs a, Ntt
     }
     const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);
     const LimbConst lc = T.limb[sl];
-    if ((lc.fp != 0) != FP) return;
+    if ((lc.fp != 0) != (AR == AR_FP)) return;
     const uint32_t row0 = (grp % tiles) * S;
     c.g = threadIdx.x / TPR;
     c.t = threadIdx.x % TPR;
@@ -1444,10 +1480,10 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_sum(SumArgs a, Ntt
     __syncthreads();  // twiddles staged
     for (uint32_t cl = 0; cl < a.n_clients; ++cl) {
         wave_lds_sync();  // previous client's tail finished reading this wave's row
-        row3_forward<FP, LOGC>(x, c, wc, wpc, lc);
+        row3_forward<AR, LOGC>(x, c, wc, wpc, lc);
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            lds[TL::at(c.g, 8 * c.t + k)] = FP ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
+            lds[TL::at(c.g, 8 * c.t + k)] = (AR == AR_FP) ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
         if (cl + 1 < a.n_clients) {
             const u64 *nxt = src0 + (size_t)(cl + 1) * a.conv_cstride;
 #pragma unroll
@@ -1546,7 +1582,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, N
     for (int dj = jn; dj < NPARTS; dj = jn) {
         jn = dj + 1 == own ? dj + 2 : dj + 1;
         wave_lds_sync();  // previous digit's products finished reading this wave's row
-        row3_forward<true, LOGC>(x, c, wc, wpc, lc);
+        row3_forward<AR_FP, LOGC>(x, c, wc, wpc, lc);
 #pragma unroll
         for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 8 * c.t + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));
         if (jn < NPARTS) {
@@ -1602,7 +1638,7 @@ struct TailOnceArgs {
     uint32_t nsel;
     uint32_t init_from_out;  // continue a running sum held in `out` (client groups)
 };
-template <int LOGC>
+template <int LOGC, int AR>
 __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_once(TailOnceArgs a, NttTables T) {
     using TL = RowT<LOGC>;
     constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
@@ -1641,7 +1677,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_once(TailOnceArgs 
         for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + TPR * k);
     }
     __syncthreads();  // twiddles staged
-    row3_forward<false, LOGC>(x, c, wc, wpc, lc);
+    row3_forward<AR, LOGC>(x, c, wc, wpc, lc);
 #pragma unroll
     for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 8 * c.t + k)] = canon8(x[k], lc.q, lc.q2);
     wave_lds_sync();
@@ -1694,19 +1730,19 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_once(TailOnceArgs 
 // inverse ROW pass of this thread's row (integer limbs): x[k] = word 8 t + k on entry (values in [0,2q)), on exit
 // x[k] = word t + TPR k in [0,2q) -- what k_ntt_row_r<INV> hands to the inverse column pass.  c.twa / c.twb hold the
 // INVERSE tables' round-A / round-B twiddles, wc / wpc the thread's inverse round-C twiddles.
-template <int LOGC>
+template <int LOGC, int AR>
 MK_D void row3_inverse_int(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], const u64 (&wpc)[7], const LimbConst &lc) {
     using TL = RowT<LOGC>;
     constexpr int S = TL::ROWS, TPR = TL::TPR, C = TL::C;
     const int a = c.t / C, cc = c.t % C;
     if (LOGC == 3) {
-        radix_inverse_any<3, false>(x, wc, wpc, lc);
+        radix_inverse_any<3, AR>(x, wc, wpc, lc);
     } else {
         u64 y0[4] = {x[0], x[1], x[2], x[3]}, y1[4] = {x[4], x[5], x[6], x[7]};
         const u64 w0[3] = {wc[0], wc[1], wc[2]}, wp0[3] = {wpc[0], wpc[1], wpc[2]};
         const u64 w1[3] = {wc[3], wc[4], wc[5]}, wp1[3] = {wpc[3], wpc[4], wpc[5]};
-        radix_inverse_any<2, false>(y0, w0, wp0, lc);
-        radix_inverse_any<2, false>(y1, w1, wp1, lc);
+        radix_inverse_any<2, AR>(y0, w0, wp0, lc);
+        radix_inverse_any<2, AR>(y1, w1, wp1, lc);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             x[k] = y0[k];
@@ -1727,7 +1763,7 @@ MK_D void row3_inverse_int(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], co
             w[(1 << s) - 1 + gg] = c.twb[e];
             wp[(1 << s) - 1 + gg] = c.twb_sh[e];
         }
-    radix_inverse_any<3, false>(x, w, wp, lc);
+    radix_inverse_any<3, AR>(x, w, wp, lc);
 #pragma unroll
     for (int k = 0; k < 8; ++k) c.lds[TL::at(c.g, 8 * C * a + C * k + cc)] = x[k];
     wave_lds_sync();
@@ -1741,7 +1777,7 @@ MK_D void row3_inverse_int(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], co
             w[(1 << s) - 1 + gg] = c.twa[e];
             wp[(1 << s) - 1 + gg] = c.twa_sh[e];
         }
-    radix_inverse_any<3, false>(x, w, wp, lc);
+    radix_inverse_any<3, AR>(x, w, wp, lc);
 }
 
 // The same fusion for the INTEGER limbs (q0 and the P limbs): forward row pass of every converted digit + eval-key
@@ -1751,7 +1787,7 @@ MK_D void row3_inverse_int(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], co
 #ifndef MK_INVP_WAVES
 #define MK_INVP_WAVES 2  // 168 VGPRs would spill 19 registers in the P instance; 2 waves measured +0.7 %
 #endif
-template <int NPARTS, int LOGC, bool INVP>
+template <int NPARTS, int LOGC, bool INVP, int AR>
 __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_inner_int(InnerArgs a, NttTables T, uint32_t L, u64 *pc,
                                                                    uint32_t K) {
     using TL = RowT<LOGC>;
@@ -1819,7 +1855,7 @@ __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_
     for (int dj = jn; dj < NPARTS; dj = jn) {
         jn = dj + 1 == own ? dj + 2 : dj + 1;
         wave_lds_sync();
-        row3_forward<false, LOGC>(x, c, wc, wpc, lc);
+        row3_forward<AR, LOGC>(x, c, wc, wpc, lc);
 #pragma unroll
         for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 8 * c.t + k)] = canon8(x[k], lc.q, lc.q2);
         if (jn < NPARTS) {
@@ -1880,7 +1916,7 @@ __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_
             for (int k = 0; k < 8; ++k) x[k] = lds[TL::at(c.g, 8 * c.t + k)];
             u64 iwc[7], iwpc[7];  // (re)loaded per component: keeps them out of the accumulators' live range
             row3_load_c_twiddles<LOGC>(itw, itw_sh, r1 + row0 + c.g, c.t, iwc, iwpc);
-            row3_inverse_int<LOGC>(x, c, iwc, iwpc, lc);
+            row3_inverse_int<LOGC, AR>(x, c, iwc, iwpc, lc);
             u64 *pd = pc + (((size_t)item * 2 + comp) * K + (sl - a.nl)) * n + tile_off + (size_t)c.g * R + c.t;
 #pragma unroll
             for (int k = 0; k < 8; ++k) st_pass(pd + TPR * k, x[k]);  // lazy [0,2q): the inverse column pass scales

@@ -212,6 +212,8 @@ void ParamSet::generate(uint32_t log_n_, uint32_t depth, uint32_t sbits, uint32_
         c.ninv_d = (double)c.ninv;
         c.ninv_qd = (double)((long double)c.ninv / (long double)q);
         c.fp = 0;  // the engine decides (needs both passes on the radix kernels)
+        c.pm = 0;  // the engine decides (integer limbs of the form 2^k - c)
+        c.pm_c = 0;
         c.pad_ = 0;
     }
 

@@ -34,6 +34,55 @@ int main() {
             }
             std::printf("ok log_n=%u L=%u K=%u alpha=%u beta=%u checksum=%llu\n", ps.log_n, ps.L, ps.K, ps.alpha, ps.beta, sum);
         }
+        // pseudo-Mersenne arithmetic of modarith.hpp (host mirror of the device code): congruence and the stated output
+        // bounds on boundary and random operands, for every eligible prime the configurations above produce plus 55-
+        // and 58-bit first moduli
+        {
+            using mk::u64;
+            typedef unsigned __int128 u128;
+            unsigned long long checked = 0;
+            u64 rng = 0x9E3779B97F4A7C15ull;
+            auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+            for (const Cfg &c : {Cfg{14, 2, 40, 60, 2}, Cfg{16, 10, 50, 60, 3}, Cfg{14, 2, 40, 55, 2}, Cfg{14, 2, 40, 58, 2},
+                                 Cfg{17, 19, 50, 60, 3}}) {
+                mk::ParamSet ps;
+                ps.generate(c.log_n, c.depth, c.sbits, c.first, c.dnum, 60, 20);
+                for (uint32_t i = 0; i < ps.D; ++i) {
+                    const u64 q = ps.moduli[i];
+                    if (q < (5ull << 48) || !mk::pm_eligible(q)) continue;
+                    mk::LimbConst lc = ps.limb[i];
+                    lc.pm = 1;
+                    lc.pm_c = (uint32_t)(((u64)1 << lc.k) - q);
+                    const mk::PmK P = mk::pm_consts(lc);
+                    const u64 U = (u64)1 << lc.k, amax = (U << 3) - 1;
+                    const u64 as[] = {0, 1, q - 1, q, U - 1, U, 2 * q, amax, amax - 1, (U << 2) + 12345, 0xffffffffull,
+                                      0x100000000ull, amax & ~0xffffffffull};
+                    const u64 ws[] = {0, 1, q - 1, q / 2, 0xffffffffull, 0x100000000ull, q - 0xffffffffull};
+                    auto check = [&](u64 a, u64 w) {
+                        const u64 wx = (u64)(((u128)w << 32) % q);
+                        const u64 r = mk::pm_lazy(a, w, wx, P);
+                        if (r % q != (u64)((u128)a * w % q)) throw std::runtime_error("pm_lazy: wrong residue");
+                        if ((u128)r * 8 >= (u128)U * 19) throw std::runtime_error("pm_lazy: result not below 2.375 * 2^k");
+                        if (r > P.q3) throw std::runtime_error("pm_lazy: result above 3q");
+                        ++checked;
+                    };
+                    for (u64 a : as)
+                        for (u64 w : ws) check(a, w);
+                    for (int it = 0; it < 20000; ++it) check(next() & amax, next() % q);
+                    const u64 xs[] = {0, q, U, ~0ull, ~0ull - 1, U - 1, amax};
+                    for (u64 x : xs) {
+                        const u64 f = mk::pm_fold(x, P);
+                        if (f % q != x % q || f >= U + (1ull << 30)) throw std::runtime_error("pm_fold");
+                    }
+                    for (int it = 0; it < 20000; ++it) {
+                        const u64 x = next(), f = mk::pm_fold(x, P);
+                        if (f % q != x % q || f >= U + (1ull << 30)) throw std::runtime_error("pm_fold");
+                    }
+                }
+            }
+            if (!checked) throw std::runtime_error("no pseudo-Mersenne prime was exercised");
+            std::printf("ok pseudo-Mersenne arithmetic (%llu products)\n", checked);
+        }
         mk::ParamSet bad;
         try {
             bad.generate(30, 1, 40, 60, 2, 60, 20);

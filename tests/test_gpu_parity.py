@@ -94,6 +94,89 @@ def test_ntt_other_sizes_and_generic_kernels(log_n, generic, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("name", ["tiny", "c3", "n17", "n11"])
+def test_ntt_extreme_residues(ctxs, name):
+    """Inputs that drive the lazy ranges of the butterflies to their bounds: every residue q - 1, alternating 0 / q - 1
+    in several periods (sums and differences of maximal terms at every stage), and q - 1 at a single position."""
+    g, o = ctxs(name)
+    ids = list(range(g.L)) + list(range(g.L, g.D))
+    pats = []
+    idx = np.arange(g.N)
+    for period in (1, 2, 16, 256, g.N // 2):
+        pats.append(((idx // period) % 2 == 0))
+    pats.append(np.ones(g.N, dtype=bool))
+    pats.append(idx == g.N - 1)
+    x = np.zeros((len(pats), len(ids), g.N), dtype=np.uint64)
+    for pi, m in enumerate(pats):
+        for j, l in enumerate(ids):
+            x[pi, j, m] = int(g.moduli[l]) - 1
+    d = g.to_device(x)
+    g.ntt_forward(d, len(pats), g.L, with_p=True)
+    fwd = d.to_host()
+    for pi in range(len(pats)):
+        for j, l in enumerate(ids):
+            assert np.array_equal(fwd[pi, j], o.ntt_fwd(l, x[pi, j])), (name, pi, l)
+    d.upload(x)
+    g.ntt_inverse(d, len(pats), g.L, with_p=True)
+    inv = d.to_host()
+    for pi in range(len(pats)):
+        for j, l in enumerate(ids):
+            assert np.array_equal(inv[pi, j], o.ntt_inv(l, x[pi, j])), (name, pi, l)
+
+
+@pytest.mark.parametrize("name,nl,C", [("c3", 12, 2), ("ref", 4, 3), ("n17", 4, 2)])
+def test_reencrypt_sum_extreme_residues(ctxs, name, nl, C):
+    """The whole key switch on maximal operands: ciphertexts and keys with every residue q - 1 (client 0) and with
+    alternating 0 / q - 1 (the others)."""
+    g, o = ctxs(name)
+    B = 1
+    cts = np.zeros((C, B, 2, nl, g.N), dtype=np.uint64)
+    evks = np.zeros((C, g.beta, 2, g.D, g.N), dtype=np.uint64)
+    idx = np.arange(g.N)
+    for c in range(C):
+        m = np.ones(g.N, dtype=bool) if c == 0 else ((idx // (1 << (3 * c))) % 2 == 0)
+        for l in range(nl):
+            cts[c, :, :, l, m] = int(g.moduli[l]) - 1
+        for l in range(g.D):
+            evks[c, :, :, l, m] = int(g.moduli[l]) - 1
+    d_out = g.empty((B, 2, nl, g.N))
+    g.reencrypt_sum(g.to_device(cts), g.to_device(evks), d_out, C, B, nl)
+    acc = o.reencrypt(cts[0, 0], evks[0])
+    for c in range(1, C):
+        acc = o.eval_add(acc, o.reencrypt(cts[c, 0], evks[c]))
+    assert np.array_equal(d_out.to_host()[0], acc)
+
+
+@pytest.mark.parametrize("first_bits", [55, 58])
+def test_first_modulus_below_60_bits(first_bits):
+    """q_0 of 55 / 58 bits is still an integer-class limb of the form 2^k - c: the pseudo-Mersenne butterflies take their
+    shifts from k.  Transforms and one key switch against the oracle."""
+    from ppqsflhe_amd import Context
+    g = Context(14, 2, 40, first_bits, dnum=2, device=0)
+    o = OracleContext(14, 2, 40, first_bits, dnum=2)
+    try:
+        assert int(g.moduli[0]).bit_length() == first_bits
+        rng = np.random.default_rng(first_bits)
+        ids = list(range(g.L)) + list(range(g.L, g.D))
+        x = rand_polys(rng, g, ids, 1)
+        x[0, 0, ::2] = int(g.moduli[0]) - 1
+        d = g.to_device(x)
+        g.ntt_forward(d, 1, g.L, with_p=True)
+        fwd = d.to_host()
+        for j, l in enumerate(ids):
+            assert np.array_equal(fwd[0, j], o.ntt_fwd(l, x[0, j])), l
+        g.ntt_inverse(d, 1, g.L, with_p=True)
+        assert np.array_equal(d.to_host(), x)
+        nl = g.L
+        ct = rand_ct(rng, g, nl, 1)
+        evk = rand_polys(rng, g, list(range(g.D)) * (2 * g.beta), 1).reshape(g.beta, 2, g.D, g.N)
+        d_out = g.empty((1, 2, nl, g.N))
+        g.reencrypt(g.to_device(ct), g.to_device(evk), d_out, 1, nl)
+        assert np.array_equal(d_out.to_host()[0], o.reencrypt(ct[0], evk))
+    finally:
+        g.close()
+
+
 def test_ntt_golden_secret_keys(ctxs, golden_dir):
     # the reference's own vectors (client_{1,2}-private.key, P4) through the HIP kernels
     import os
@@ -394,7 +477,9 @@ def test_reencrypt_sum(ctxs, name, nl, C, B):
                                  {"MKCKKS_QSUM_GROUP": "1"},
                                  {"MKCKKS_QSUM_GEOM": "2"},       # two-round k_qsum_fp (16 words per thread)
                                  {"MKCKKS_QSUM_GEOM": "2", "MKCKKS_QSUM_GROUP": "2"},
-                                 {"MKCKKS_SUM_ONE_LANE": "1"}])   # clients strictly one after the other
+                                 {"MKCKKS_SUM_ONE_LANE": "1"},    # clients strictly one after the other
+                                 {"MKCKKS_NO_PM": "1"},           # Shoup butterflies on q_0 and the P limbs
+                                 {"MKCKKS_NO_PM": "1", "MKCKKS_QSUM": "0"}])
 def test_unfused_kernel_paths_stay_bit_exact(ctxs, monkeypatch, env):
     """Every non-default kernel path the library keeps behind a switch (other ring sizes fall back to them, A/B
     measurements use them): a context created under the switch must give the same bits as the default context and as

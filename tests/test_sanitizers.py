@@ -43,6 +43,8 @@ def test_params_under_asan_ubsan():
                        env=ENV, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok log_n=") == 5 and "invalid parameters are refused" in r.stdout
+    # the butterflies' pseudo-Mersenne products and folds (modarith.hpp is host + device code): residues and range bounds
+    assert "ok pseudo-Mersenne arithmetic" in r.stdout
 
 
 def test_host_parsers_on_wellformed_inputs(selftest, tmp_path, golden_dir):

@@ -33,6 +33,19 @@ __global__ void k(u64 *out, u64 seed) {
             a2 = a2 * w - __umul64hi(a2, wp) * q; a3 = a3 * w - __umul64hi(a3, wp) * q;
         } else if (OP == 7) {  // v_add_co / 64-bit add (reference)
             a0 += b; a1 += b; a2 += b; a3 += b; a0 ^= a1; a2 ^= a3;
+        } else if (OP == 9) {  // pseudo-Mersenne lazy modmul: q = 2^60 - c, companion wx = w * 2^31 mod q
+            const u64 q = 1152921504606584833ull, w = b % q, wx = (u64)(((unsigned __int128)w << 31) % q);
+            const uint32_t c = (uint32_t)((1ull << 60) - q);
+            auto pm = [&](u64 a) {
+                const uint32_t al = (uint32_t)a & 0x7fffffffu, ah = (uint32_t)(a >> 31);
+                u64 y = (u64)al * (uint32_t)w + (u64)ah * (uint32_t)wx;
+                u64 z = (u64)al * (uint32_t)(w >> 32) + (y >> 32);
+                z = (u64)ah * (uint32_t)(wx >> 32) + z;
+                const uint32_t hi = (uint32_t)(z >> 28);
+                const u64 lo = ((z & 0x0fffffffull) << 32) | (uint32_t)y;
+                return (u64)hi * c + lo;
+            };
+            a0 = pm(a0); a1 = pm(a1); a2 = pm(a2); a3 = pm(a3);
         } else if (OP == 8) {  // v_mul_u32_u24-style: 24-bit multiply
             x0 = __umul24(x0, xb) + 1; x1 = __umul24(x1, xb) + 1; x2 = __umul24(x2, xb) + 1; x3 = __umul24(x3, xb) + 1;
         }
@@ -68,5 +81,6 @@ int main() {
     run<6>("shoup_lazy modmul", 4);
     run<7>("add64+xor", 6);
     run<8>("v_mul_u32_u24 (+add)", 4);
+    run<9>("pseudo-Mersenne modmul", 4);
     return 0;
 }

@@ -555,9 +555,11 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device), knobs
             std::memcpy(&wsh[k], &wq, 8);
         }
     };
-    auto as_pm = [&](uint32_t i) {  // Shoup companion -> w * 2^32 mod q
-        const u64 q = ps_.moduli[i];
-        for (uint32_t k = 0; k < n; ++k) wsh[k] = (u64)(((u128)w[k] << 32) % q);
+    auto as_pm = [&](uint32_t i) {  // (w, Shoup companion) -> (w << t, (w * 2^32 mod q) << t), see pm_lazy
+        for (uint32_t k = 0; k < n; ++k) {
+            wsh[k] = pm_tw_companion(w[k], ps_.limb[i]);
+            w[k] = pm_tw(w[k], ps_.limb[i]);
+        }
     };
     for (uint32_t i = 0; i < D; ++i) {
         ps_.twiddles(i, false, w, wsh);

@@ -111,11 +111,11 @@ MK_HD u64 shoup_mul(u64 a, u64 w, u64 wp, u64 q) { return csub(shoup_lazy(a, w, 
 // ---- pseudo-Mersenne limbs: q = 2^k - c, c <= 2^(k-34), U := 2^k --------------------------------------------------
 // gfx950 issues v_mad_u64_u32 at the rate of a 32-bit add (tools/ubench_intmul.hip), so what counts is the NUMBER of
 // instructions.  Shoup's product is 3 multiplies for the quotient's high word + 2 x 3 for the two low products plus
-// their glue (~15 instructions); with 2^k = c (mod q) a product is reduced by folding its bits above k back in with one
-// small multiply: 5 v_mad_u64_u32 + 6 of glue.
+// their glue; with 2^k = c (mod q) a product is reduced by folding its bits above k back in with one small multiply:
+// 5 v_mad_u64_u32 + the 32-bit word shuffling between them.
 struct PmK {           // wave-uniform shifts / masks / constants of one limb
     uint32_t c, c2;    // c, 2c
-    uint32_t s_hi, m_hi;  // split of a 96-bit product's upper 64 bits at bit k+1: shift k+1-32, mask 2^(k+1-32) - 1
+    uint32_t t;        // 63 - k: the NTT tables of such a limb hold w << t and (w * 2^32 mod q) << t
     uint32_t s_f, m_f;    // split of a 64-bit word at bit k: shift k-32, mask 2^(k-32) - 1
     u64 q3;            // 3q >= any pm_lazy result (offset of the butterflies' subtractions)
 };
@@ -123,33 +123,46 @@ MK_HD PmK pm_consts(const LimbConst &L) {
     PmK p;
     p.c = L.pm_c;
     p.c2 = 2 * L.pm_c;
-    p.s_hi = L.k + 1 - 32;
-    p.m_hi = (1u << p.s_hi) - 1u;
+    p.t = 63 - L.k;
     p.s_f = L.k - 32;
     p.m_f = (1u << p.s_f) - 1u;
     p.q3 = 3 * L.q;
     return p;
 }
+// table entries of a pseudo-Mersenne limb for the twiddle w (host side)
+MK_HD u64 pm_tw(u64 w, const LimbConst &L) { return w << (63 - L.k); }
+inline u64 pm_tw_companion(u64 w, const LimbConst &L) { return (u64)(((u128)w << 32) % L.q) << (63 - L.k); }
 // x (any 64-bit word) -> x mod q in [0, U + 2^30):  (x mod 2^k) + (x >> k) c, and (x >> k) c < 2^(64-k) 2^(k-34).
 MK_HD u64 pm_fold(u64 x, const PmK &P) {
     const uint32_t xh = (uint32_t)(x >> 32);
     const u64 lo = ((u64)(xh & P.m_f) << 32) | (uint32_t)x;
     return (u64)(xh >> P.s_f) * P.c + lo;
 }
-// a * w mod q, lazy, for a < 8U = 2^(k+3), w < q and the companion wx = w * 2^32 mod q:
-//   S = a_lo w + a_hi wx  = a w (mod q),  S < 2^32 U + 2^(k-29) U <= 1.5 * 2^32 U   (96 bits: z : low word of y1)
-//   S = hi 2^(k+1) + lo,  hi < 1.5 * 2^31,  2^(k+1) = 2c (mod q)  ->  lo + hi 2c < 2U + 0.375U.
-// Result in [0, 2.375U).  y1 cannot wrap: a_hi < 2^31 and wx_lo < 2^32.
-MK_HD u64 pm_lazy(u64 a, u64 w, u64 wx, const PmK &P) {
+// {high word of y, 0} as a register pair in ONE instruction (the compiler would build it from two moves)
+MK_HD u64 hi32_pair(u64 y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 r;
+    asm("v_lshrrev_b64 %0, 32, %1" : "=v"(r) : "v"(y));
+    return r;
+#else
+    return y >> 32;
+#endif
+}
+// a * w mod q, lazy, for a < 8U = 2^(k+3), from the table entries wt = w << t and wxt = (w * 2^32 mod q) << t (t = 63 - k):
+//   S' = a_lo wt + a_hi wxt = 2^t S,  S = a_lo w + a_hi (w 2^32 mod q) = a w (mod q),  S < 2^32 U + 2^(k-29) U <= 1.5 * 2^32 U
+//   the fold position k+1 of S is bit 64 of S' (96 bits: z : low word of y1):  hi = S >> (k+1) = high word of z < 1.5 * 2^31,
+//   lo = S mod 2^(k+1) = (S' mod 2^64) >> t,  and 2^(k+1) = 2c (mod q)  ->  lo + hi 2c < 2U + 0.375U.
+// Result in [0, 2.375U).  No partial sum wraps: a_lo wt_lo < 2^64; a_lo wt_hi + 2^32 < 2^64 (wt < 2^63); a_hi < 2^31 keeps
+// a_hi wxt_lo + 2^32 below 2^64; z ends as floor(S' / 2^32) < 1.5 * 2^63.
+MK_HD u64 pm_lazy(u64 a, u64 wt, u64 wxt, const PmK &P) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
-    const u64 y0 = (u64)a0 * (uint32_t)w;
-    u64 z = (u64)a0 * (uint32_t)(w >> 32) + (y0 >> 32);
-    const u64 y1 = (u64)a1 * (uint32_t)wx + (uint32_t)y0;
-    z += (u64)a1 * (uint32_t)(wx >> 32);
-    z += y1 >> 32;
-    const uint32_t hi = (uint32_t)(z >> P.s_hi);
-    const u64 lo = ((u64)((uint32_t)z & P.m_hi) << 32) | (uint32_t)y1;
-    return (u64)hi * P.c2 + lo;
+    const u64 y0 = (u64)a0 * (uint32_t)wt;
+    u64 z = (u64)a0 * (uint32_t)(wt >> 32) + hi32_pair(y0);
+    const u64 y1 = (u64)a1 * (uint32_t)wxt + (u64)(uint32_t)y0;
+    z = (u64)a1 * (uint32_t)(wxt >> 32) + z;
+    z += hi32_pair(y1);
+    const u64 lo = (((u64)(uint32_t)z << 32) | (uint32_t)y1) >> P.t;
+    return (u64)(uint32_t)(z >> 32) * P.c2 + lo;
 }
 
 // Barrett reduction of a 128-bit x = hi:lo with x < 2^(k+62) (k = bitlen q) to [0,q).

@@ -59,8 +59,7 @@ int main() {
                                       0x100000000ull, amax & ~0xffffffffull};
                     const u64 ws[] = {0, 1, q - 1, q / 2, 0xffffffffull, 0x100000000ull, q - 0xffffffffull};
                     auto check = [&](u64 a, u64 w) {
-                        const u64 wx = (u64)(((u128)w << 32) % q);
-                        const u64 r = mk::pm_lazy(a, w, wx, P);
+                        const u64 r = mk::pm_lazy(a, mk::pm_tw(w, lc), mk::pm_tw_companion(w, lc), P);
                         if (r % q != (u64)((u128)a * w % q)) throw std::runtime_error("pm_lazy: wrong residue");
                         if ((u128)r * 8 >= (u128)U * 19) throw std::runtime_error("pm_lazy: result not below 2.375 * 2^k");
                         if (r > P.q3) throw std::runtime_error("pm_lazy: result above 3q");

@@ -130,10 +130,14 @@ def cpu_baseline(args, log):
                       f"1-thread leg {dt1:.1f}s on {max(2, args.cpu_sample // 48)} ciphertexts"}
 
 
-def valu_ceiling(N, log_n, L, K, beta, alpha, n_clients, fp_limbs_q):
+INT_BUTTERFLY_CYCLES = {False: 90.9, True: 77.6}  # Shoup | pseudo-Mersenne (profiles/r02_ubench_fpmod.txt)
+
+
+def valu_ceiling(N, log_n, L, K, beta, alpha, n_clients, fp_limbs_q, int_pm=True):
     """Secondary ceiling: the path is 64-bit modular arithmetic on a chip without a 64-bit
-    multiplier.  Work per unit x measured cycles per wave-operation (profiles/r01_ubench_intmul.txt, r01_ubench_fpmod.txt:
-    fp64 butterfly 61, Shoup butterfly 90, v_mad_u64_u32 5.3, v_fma_f64 4.4 cycles) against 1024 SIMDs x 2.4 GHz."""
+    multiplier.  Work per unit x measured cycles per wave-operation (profiles/r02_ubench_intmul.txt, r02_ubench_fpmod.txt:
+    fp64 butterfly 61, integer butterfly 90.9 (Shoup) or 77.6 (pseudo-Mersenne, the arithmetic mkckks_ctx_arith reports
+    for the 60-bit limbs), v_mad_u64_u32 5.3, v_fma_f64 4.4 cycles) against 1024 SIMDs x 2.4 GHz."""
     D = L + K
     bf = N // 2 * log_n                                   # butterflies of one limb transform
     int_q = L - fp_limbs_q                                # integer-class Q limbs (60-bit q_0)
@@ -143,11 +147,12 @@ def valu_ceiling(N, log_n, L, K, beta, alpha, n_clients, fp_limbs_q):
     resc_int, resc_fp = (2 * int_q) / n_clients, (2 + 2 * (fp_limbs_q - 1)) / n_clients  # rescale, amortised
     conv_macs = (beta * alpha * (D - alpha) + 2 * K * L) * N   # ModUp + ModDown base-conversion MACs
     inner = 2 * beta * D * N                                # eval-key mul-adds
-    cyc = ((t_int + resc_int) * bf * 90.0 + (t_fp + resc_fp) * bf * 61.0 + conv_macs * 4 * 5.3
+    cyc = ((t_int + resc_int) * bf * INT_BUTTERFLY_CYCLES[bool(int_pm)] + (t_fp + resc_fp) * bf * 61.0 + conv_macs * 4 * 5.3
            + inner * (fp_limbs_q / L * 6 * 4.4 + (1 - fp_limbs_q / L) * 30.0)) / 64.0
     return 1024 * 2.4e9 / cyc, {
         "limb_transforms_int": t_int, "limb_transforms_fp64": t_fp, "butterflies_per_limb": bf,
-        "base_conv_macs": conv_macs, "inner_product_muladds": inner, "simd_cycles_per_unit": cyc}
+        "base_conv_macs": conv_macs, "inner_product_muladds": inner, "simd_cycles_per_unit": cyc,
+        "int_butterfly": "pseudo-mersenne" if int_pm else "shoup", "int_butterfly_cycles": INT_BUTTERFLY_CYCLES[bool(int_pm)]}
 
 
 def verify_exchange(torch, dist, ctx, pipe, agg, out, ct_in, evk, C, B, Bs, L, world, rank, inv_n, log):
@@ -410,8 +415,9 @@ def main():
                                   f"builder run ({rec[key].get('profile', 'see profiles/')}), NOT measured in this run")
         except Exception:
             traffic = None
-    fp_q = sum(1 for i in range(L) if int(ctx.moduli[i]) < (5 << 48))  # limbs on the fp64 kernel instances
-    ceil_ct_s, ceil_terms = valu_ceiling(N, args.log_n, L, K, beta, ctx.alpha, n_summed, fp_q)
+    fp_q = int(sum(1 for i in range(L) if int(ctx.arith[i]) == 1))
+    int_pm = any(int(a) == 2 for a in ctx.arith)
+    ceil_ct_s, ceil_terms = valu_ceiling(N, args.log_n, L, K, beta, ctx.alpha, n_summed, fp_q, int_pm)
     per_gpu = C * B / step_s_gpu
 
     shard_txt = ("" if world == 1 else
@@ -440,10 +446,11 @@ def main():
                                    "frac": per_gpu / ceil_ct_s, "terms": ceil_terms,
                                    "derivation": "gfx950 has no 64-bit multiplier: per unit, limb transforms x N/2 log2 N "
                                                  "butterflies x measured cycles per wave-operation (fp64-FMA butterfly 61, "
-                                                 "Shoup butterfly on v_mad_u64_u32 90), base-conversion MACs x 4 "
+                                                 "integer butterfly on v_mad_u64_u32: 90.9 Shoup / 77.6 pseudo-Mersenne, "
+                                                 "whichever mkckks_ctx_arith reports), base-conversion MACs x 4 "
                                                  "v_mad_u64_u32 x 5.3, eval-key mul-adds x (6 v_fma_f64 x 4.4 | 30), / 64 "
                                                  "lanes, against 1024 SIMDs x 2.4 GHz; cycle figures: "
-                                                 "profiles/r01_ubench_intmul.txt, profiles/r01_ubench_fpmod.txt"}},
+                                                 "profiles/r02_ubench_intmul.txt, profiles/r02_ubench_fpmod.txt"}},
     }
     if rank == 0 and world == 1 and not args.no_cpu:
         try:

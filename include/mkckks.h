@@ -75,6 +75,13 @@ int mkckks_ctx_destroy(mkckks_ctx *c);
 int mkckks_ctx_info(const mkckks_ctx *c, mkckks_info *out);
 int mkckks_ctx_moduli(const mkckks_ctx *c, uint64_t *h_out /*D*/);
 int mkckks_ctx_roots(const mkckks_ctx *c, uint64_t *h_out /*D*/);
+/* arithmetic the device kernels use per limb (diagnostics, bench.py's instruction-issue ceiling): 0 = 64-bit integer
+ * with Shoup/Harvey butterflies, 1 = fp64 (moduli below 1.25 * 2^50), 2 = 64-bit integer with pseudo-Mersenne
+ * butterflies (q = 2^k - c; OpenFHE's 60-bit primes).  Results are the same bits in every class. */
+#define MKCKKS_ARITH_INT 0
+#define MKCKKS_ARITH_FP64 1
+#define MKCKKS_ARITH_PM 2
+int mkckks_ctx_arith(const mkckks_ctx *c, uint8_t *h_out /*D*/);
 /* CryptoParametersCKKSRNS::GetScalingFactorReal / RealBig (level = #dropped limbs) */
 int mkckks_scaling_factor(const mkckks_ctx *c, uint32_t level, int big, double *out);
 /* stream: a hipStream_t passed as void* (NULL = default stream) */

@@ -45,6 +45,7 @@ SYMBOLS = {
     "mkckks_ctx_info": (_int, [_vp, C.POINTER(_Info)]),
     "mkckks_ctx_moduli": (_int, [_vp, _u64p]),
     "mkckks_ctx_roots": (_int, [_vp, _u64p]),
+    "mkckks_ctx_arith": (_int, [_vp, _vp]),
     "mkckks_scaling_factor": (_int, [_vp, _u32, _int, C.POINTER(_dbl)]),
     "mkckks_set_stream": (_int, [_vp, _vp]),
     "mkckks_sync": (_int, [_vp]),
@@ -223,6 +224,9 @@ class Context:
         self.roots = np.zeros(self.D, dtype=np.uint64)
         self._check(self._L.mkckks_ctx_moduli(self._h, self.moduli.ctypes.data))
         self._check(self._L.mkckks_ctx_roots(self._h, self.roots.ctypes.data))
+        # arithmetic class of every limb on the device: 0 integer (Shoup), 1 fp64, 2 integer (pseudo-Mersenne)
+        self.arith = np.zeros(self.D, dtype=np.uint8)
+        self._check(self._L.mkckks_ctx_arith(self._h, self.arith.ctypes.data))
 
     def _check(self, rc):
         if rc != 0:

@@ -88,6 +88,15 @@ int mkckks_ctx_moduli(const mkckks_ctx *c, uint64_t *h_out) {
     });
 }
 
+int mkckks_ctx_arith(const mkckks_ctx *c, uint8_t *h_out) {
+    return guarded([&] {
+        need(c && h_out, "null argument");
+        const auto &limb = c->eng->params().limb;
+        for (size_t i = 0; i < limb.size(); ++i)
+            h_out[i] = limb[i].fp ? MKCKKS_ARITH_FP64 : (limb[i].pm ? MKCKKS_ARITH_PM : MKCKKS_ARITH_INT);
+    });
+}
+
 int mkckks_ctx_roots(const mkckks_ctx *c, uint64_t *h_out) {
     return guarded([&] {
         need(c && h_out, "null argument");

@@ -46,6 +46,9 @@ def test_secondary_ceiling_terms():
     assert t["base_conv_macs"] == (3 * 4 * 12 + 2 * 4 * 12) * N                  # 9.4 M + 6.3 M
     assert t["inner_product_muladds"] == 2 * 3 * 16 * N                          # 6.3 M
     assert 30e3 < ceil < 60e3                                                    # ct/s per GPU
+    assert t["int_butterfly"] == "pseudo-mersenne"
+    ceil_shoup, t2 = b.valu_ceiling(N, 16, L, K, beta, alpha, 8, 11, int_pm=False)
+    assert t2["int_butterfly"] == "shoup" and ceil_shoup < ceil                  # dearer integer butterflies, lower ceiling
 
 
 def test_cpu_model_string():

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cmath>
+#include "../ppqsflhe_amd/csrc/modarith.hpp"  // pm_lazy / pm_fold: the library's own pseudo-Mersenne arithmetic
 typedef uint64_t u64;
 typedef unsigned __int128 u128;
 
@@ -65,6 +66,13 @@ __global__ void k_rate(double *out, double seed) {
         } else if (OP == 1) {  // integer butterfly (c4 correction)
 #define INB(x, y) { u64 t = x + (0 - q4); u64 u = (long long)t < 0 ? x : t; u64 h = __umul64hi(y, wp); u64 v = y * wi - h * qi; x = u + v; y = u - v + q2; }
             INB(a0, b0) INB(a1, b1) INB(a2, b2) INB(a3, b3)
+        } else if (OP == 3) {  // pseudo-Mersenne butterfly on a 60-bit prime, x folded every 2nd iteration (radix_forward_pm)
+            mk::LimbConst lc{};
+            lc.q = 1152921504606584833ull; lc.k = 60; lc.pm_c = (uint32_t)((1ull << 60) - lc.q);
+            const mk::PmK P = mk::pm_consts(lc);
+            const u64 wt = wi << 3, wxt = (u64)(((u128)wi << 32) % lc.q) << 3;
+#define PMB(x, y) { u64 u = (i & 1) ? x : mk::pm_fold(x, P); u64 v = mk::pm_lazy(y, wt, wxt, P); x = u + v; y = u - v + P.q3; }
+            PMB(a0, b0) PMB(a1, b1) PMB(a2, b2) PMB(a3, b3)
         } else if (OP == 2) {  // rint rate
             x0 = rint(x0 * 1.0000001) + 0.25; x1 = rint(x1 * 1.0000001) + 0.25; x2 = rint(x2 * 1.0000001) + 0.25; x3 = rint(x3 * 1.0000001) + 0.25;
         }
@@ -108,5 +116,6 @@ int main() {
     rate<0>("fp64 butterfly (+reduce/2)", 4);
     rate<1>("int Shoup butterfly", 4);
     rate<2>("rint+mul+add", 4);
+    rate<3>("int pseudo-Mersenne butterfly", 4);
     return 0;
 }

@@ -118,6 +118,7 @@ struct PmK {           // wave-uniform shifts / masks / constants of one limb
     uint32_t t;        // 63 - k: the NTT tables of such a limb hold w << t and (w * 2^32 mod q) << t
     uint32_t s_f, m_f;    // split of a 64-bit word at bit k: shift k-32, mask 2^(k-32) - 1
     u64 q3;            // 3q >= any pm_lazy result (offset of the butterflies' subtractions)
+    uint32_t c64;      // 2^64 mod q = c 2^(64-k) <= 2^30 (pm_reduce128)
 };
 MK_HD PmK pm_consts(const LimbConst &L) {
     PmK p;
@@ -127,6 +128,7 @@ MK_HD PmK pm_consts(const LimbConst &L) {
     p.s_f = L.k - 32;
     p.m_f = (1u << p.s_f) - 1u;
     p.q3 = 3 * L.q;
+    p.c64 = L.pm_c << (64 - L.k);
     return p;
 }
 // table entries of a pseudo-Mersenne limb for the twiddle w (host side)
@@ -163,6 +165,19 @@ MK_HD u64 pm_lazy(u64 a, u64 wt, u64 wxt, const PmK &P) {
     z += hi32_pair(y1);
     const u64 lo = (((u64)(uint32_t)z << 32) | (uint32_t)y1) >> P.t;
     return (u64)(uint32_t)(z >> 32) * P.c2 + lo;
+}
+
+// X = hi:lo -> X mod q in [0, q), for X < 2^(2k+6) (a sum of up to 6 products of a lazy word < 8U and a residue): the high
+// word is folded with 2^64 = c64 (mod q) into Y = m1 2^32 + (low word of m0) < 2^(2k-28) + 2^64, Y is folded at bit k
+// (Y >> k < 2^32) into r < U + 2^32 c <= 1.25U, one conditional subtraction finishes.  11 instructions where Barrett's
+// quotient estimate (high product, low product, two corrections) takes about 25.
+MK_HD u64 pm_reduce128(u64 hi, u64 lo, const PmK &P, u64 q) {
+    const u64 m0 = (u64)(uint32_t)hi * P.c64 + (u64)(uint32_t)lo;
+    u64 m1 = (u64)(uint32_t)(hi >> 32) * P.c64 + hi32_pair(lo);
+    m1 += hi32_pair(m0);
+    const uint32_t yh = (uint32_t)(m1 >> P.s_f);
+    const u64 ylo = ((u64)((uint32_t)m1 & P.m_f) << 32) | (uint32_t)m0;
+    return csub((u64)yh * P.c + ylo, q);
 }
 
 // Barrett reduction of a 128-bit x = hi:lo with x < 2^(k+62) (k = bitlen q) to [0,q).

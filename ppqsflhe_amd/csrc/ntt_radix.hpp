@@ -1857,7 +1857,8 @@ __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_
         wave_lds_sync();
         row3_forward<AR, LOGC>(x, c, wc, wpc, lc);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 8 * c.t + k)] = canon8(x[k], lc.q, lc.q2);
+        // AR_PM: the lazy words (< 7.001U) go into the products as they are -- pm_reduce128 takes 6 x 2^63 x q
+        for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 8 * c.t + k)] = AR == AR_PM ? x[k] : canon8(x[k], lc.q, lc.q2);
         if (jn < NPARTS) {
             const u64 *src = dig0 + (size_t)jn * a.ext * n;
 #pragma unroll
@@ -1895,8 +1896,14 @@ __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_
         for (int i = 0; i < PAIRS; ++i) {
             const u64 hx = comp ? h1[2 * i] : h0[2 * i], lx = comp ? l1[2 * i] : l0[2 * i];
             const u64 hy = comp ? h1[2 * i + 1] : h0[2 * i + 1], ly = comp ? l1[2 * i + 1] : l0[2 * i + 1];
-            res[i].x = NPARTS <= 4 ? reduce_sum4(hx, lx, lc) : reduce_wide(hx, lx, lc);
-            res[i].y = NPARTS <= 4 ? reduce_sum4(hy, ly, lc) : reduce_wide(hy, ly, lc);
+            if (AR == AR_PM) {
+                const PmK P = pm_consts(lc);
+                res[i].x = pm_reduce128(hx, lx, P, lc.q);
+                res[i].y = pm_reduce128(hy, ly, P, lc.q);
+            } else {
+                res[i].x = NPARTS <= 4 ? reduce_sum4(hx, lx, lc) : reduce_wide(hx, lx, lc);
+                res[i].y = NPARTS <= 4 ? reduce_sum4(hy, ly, lc) : reduce_wide(hy, ly, lc);
+            }
         }
         if (!inv) {
             u64 *td = a.til + (a.til_compact ? ((size_t)item * 2 + comp) * a.nsel + grp / tiles

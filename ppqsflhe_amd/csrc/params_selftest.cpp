@@ -68,6 +68,18 @@ int main() {
                     for (u64 a : as)
                         for (u64 w : ws) check(a, w);
                     for (int it = 0; it < 20000; ++it) check(next() & amax, next() % q);
+                    // 128-bit accumulators of the eval-key inner product: up to 6 products (lazy word < 8U) x (residue < q)
+                    for (int it = 0; it < 20000; ++it) {
+                        u128 X = 0;
+                        const int terms = 1 + it % 6;
+                        for (int t = 0; t < terms; ++t) {
+                            const u64 a = (it % 5 == 0) ? amax : (next() & amax), b = (it % 7 == 0) ? q - 1 : next() % q;
+                            X += (u128)a * b;
+                        }
+                        const u64 r = mk::pm_reduce128((u64)(X >> 64), (u64)X, P, q);
+                        if (r != (u64)(X % q)) throw std::runtime_error("pm_reduce128");
+                        ++checked;
+                    }
                     const u64 xs[] = {0, q, U, ~0ull, ~0ull - 1, U - 1, amax};
                     for (u64 x : xs) {
                         const u64 f = mk::pm_fold(x, P);

@@ -119,6 +119,7 @@ struct PmK {           // wave-uniform shifts / masks / constants of one limb
     uint32_t s_f, m_f;    // split of a 64-bit word at bit k: shift k-32, mask 2^(k-32) - 1
     u64 q3;            // 3q >= any pm_lazy result (offset of the butterflies' subtractions)
     uint32_t c64;      // 2^64 mod q = c 2^(64-k) <= 2^30 (pm_reduce128)
+    uint32_t e60;      // 2^60 mod q = c 2^(60-k) <= 2^26 (pm_reduce_cols)
 };
 MK_HD PmK pm_consts(const LimbConst &L) {
     PmK p;
@@ -129,6 +130,7 @@ MK_HD PmK pm_consts(const LimbConst &L) {
     p.m_f = (1u << p.s_f) - 1u;
     p.q3 = 3 * L.q;
     p.c64 = L.pm_c << (64 - L.k);
+    p.e60 = L.pm_c << (60 - L.k);
     return p;
 }
 // table entries of a pseudo-Mersenne limb for the twiddle w (host side)
@@ -279,6 +281,21 @@ MK_HD u64 reduce_cols_lazy(const Cols &c, const LimbConst &L) {  // result in [0
     const u64 y = (c.c0 >> L.sh) + (e1 >= 0 ? (c.c1 << e1) : (c.c1 >> (-e1))) + (c.c2 << (60 - L.sh));
     const u64 qh = mulhi64(y, L.mu);
     return lo - qh * L.q;
+}
+// the same triple on a pseudo-Mersenne limb (columns of <= 4 products a_i b_i, a_i < 2^60, b_i < q), lazy result below
+// 2.1U (the first butterfly stage takes < 8U):
+//   S = A + t 2^60,  A = c0 + (c1 mod 2^30) 2^30 < 2^62 + 2^60,  t = c2 + (c1 >> 30) < 2^(k+2) + 2^33,  2^60 = e60 (mod q)
+//   T = t e60 < 2^(k+2) c 2^(60-k) + ... < 2^(k+29) is folded at bit k: (T mod 2^k) + (T >> k) c < U + 2^29 c < 1.01U;
+//   A is folded below 1.001U.
+MK_HD u64 pm_reduce_cols(const Cols &c, const PmK &P) {
+    const u64 t = c.c2 + (c.c1 >> 30);
+    const u64 m0 = (u64)(uint32_t)t * P.e60;
+    const u64 m1 = (u64)(uint32_t)(t >> 32) * P.e60 + hi32_pair(m0);  // T = m1 2^32 + low word of m0
+    const uint32_t yh = (uint32_t)(m1 >> P.s_f);
+    const u64 ylo = ((u64)((uint32_t)m1 & P.m_f) << 32) | (uint32_t)m0;
+    const u64 a = c.c0 + ((c.c1 & 0x3FFFFFFFull) << 30);
+    // (a wave-uniform "skip the fold when k = 60" costs 36 more registers in k_conv_col than the three instructions save)
+    return (u64)yh * P.c + ylo + pm_fold(a, P);
 }
 MK_HD u64 reduce_cols(const Cols &c, const LimbConst &L) {
     return csub(csub(reduce_cols_lazy(c, L), L.q2), L.q);

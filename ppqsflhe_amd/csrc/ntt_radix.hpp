@@ -456,7 +456,7 @@ MK_D constexpr bool src_is_double(int i) {
     return SRCMODE == 1 || (SRCMODE == 2 && i > 0);
 }
 template <int LOG_H, int N_IN, int AR, typename CONV, int SRCMODE = 0>
-__global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T, CONV cv) {
+__global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTables T, CONV cv) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
     static_assert(SRCMODE == 0 || N_IN <= 4, "double sources: at most 4 per digit");
@@ -529,7 +529,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_conv_col(ConvIo io, NttTables T
                     }
                     mac_cols(acc, a0, a1, h0[i], h1[i]);
                 }
-                x[k] = reduce_cols_lazy(acc, lc);  // < 4q: the first butterfly stage accepts < 8q
+                // < 4q (< 2.1U on a pseudo-Mersenne limb): the first butterfly stage accepts < 8q
+                x[k] = AR == AR_PM ? pm_reduce_cols(acc, pm_consts(lc)) : reduce_cols_lazy(acc, lc);
                 if (AR == AR_FP) x[k] = dbits(fp_reduce((double)x[k], lc.qd, lc.qinv));  // < 4q < 2^53: exact in a double
             }
         }

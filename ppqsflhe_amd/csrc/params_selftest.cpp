@@ -80,6 +80,22 @@ int main() {
                         if (r != (u64)(X % q)) throw std::runtime_error("pm_reduce128");
                         ++checked;
                     }
+                    // column sums of up to 4 products of 60-bit numbers split in 30-bit halves (base conversion)
+                    for (int it = 0; it < 20000; ++it) {
+                        mk::Cols cs{0, 0, 0};
+                        u128 X = 0;
+                        for (int t = 0; t < 1 + it % 4; ++t) {
+                            const u64 a = (it % 5 == 0) ? (1ull << 60) - 1 : next() >> 4, b = (it % 3 == 0) ? q - 1 : next() % q;
+                            uint32_t a0, a1, b0, b1;
+                            mk::split30(a, a0, a1);
+                            mk::split30(b, b0, b1);
+                            mk::mac_cols(cs, a0, a1, b0, b1);
+                            X += (u128)a * b;
+                        }
+                        const u64 r = mk::pm_reduce_cols(cs, P);
+                        if (r % q != (u64)(X % q) || r >= 2 * U + (U >> 3)) throw std::runtime_error("pm_reduce_cols");
+                        ++checked;
+                    }
                     const u64 xs[] = {0, q, U, ~0ull, ~0ull - 1, U - 1, amax};
                     for (u64 x : xs) {
                         const u64 f = mk::pm_fold(x, P);

@@ -479,7 +479,11 @@ def test_reencrypt_sum(ctxs, name, nl, C, B):
                                  {"MKCKKS_QSUM_GEOM": "2", "MKCKKS_QSUM_GROUP": "2"},
                                  {"MKCKKS_SUM_ONE_LANE": "1"},    # clients strictly one after the other
                                  {"MKCKKS_NO_PM": "1"},           # Shoup butterflies on q_0 and the P limbs
-                                 {"MKCKKS_NO_PM": "1", "MKCKKS_QSUM": "0"}])
+                                 {"MKCKKS_NO_PM": "1", "MKCKKS_QSUM": "0"},
+                                 {"MKCKKS_QSUM_GEOM": "4"},       # three-round k_qsum3_fp at 2 waves per SIMD
+                                 {"MKCKKS_NO_FP64": "1"},         # integer (Shoup) arithmetic on every limb
+                                 {"MKCKKS_NO_FP64": "1", "MKCKKS_QSUM": "0"},
+                                 {"MKCKKS_GENERIC_NTT": "1"}])    # LDS-stage kernels for both passes, nothing fused
 def test_unfused_kernel_paths_stay_bit_exact(ctxs, monkeypatch, env):
     """Every non-default kernel path the library keeps behind a switch (other ring sizes fall back to them, A/B
     measurements use them): a context created under the switch must give the same bits as the default context and as

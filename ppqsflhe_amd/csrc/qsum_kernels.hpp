@@ -320,8 +320,10 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
                 }
             }
         }
+        int nd = ND;
+        if (ND == 1) asm volatile("" : "+s"(nd));  // two digits: keep this a loop -- inlined into the client loop it costs 50 more spilled registers
 #pragma unroll 1
-        for (int u = 0; u < ND; ++u) {
+        for (int u = 0; u < nd; ++u) {
             const bool last_u = u == ND - 1;
             transform(x, last_u ? src_of(cl + 1, 0) : src_of(cl, u + 1));
             const int dj = u < own ? u : u + 1;

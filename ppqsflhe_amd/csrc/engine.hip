@@ -829,18 +829,27 @@ static void launch_col(const NttIo &io0, const NttTables &T, uint32_t n_polys, c
     switch (fast_log_h(T.log_r1, r2)) {
         case 4:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_col_r<4, INV, decltype(ar)::value><<<dim3(r2 / 16, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); }); },
-                [&](hipStream_t s) { k_ntt_col_r<4, INV, true><<<dim3(r2 / 16, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack); });
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
+                    k_ntt_col_r<4, INV, decltype(ar)::value>
+                        <<<dim3(r2 / 16, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack);
+                }); },
+                [&](hipStream_t s) { k_ntt_col_r<4, INV, AR_FP><<<dim3(r2 / 16, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack); });
             break;
         case 3:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_col_r<3, INV, decltype(ar)::value><<<dim3(r2 / 32, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); }); },
-                [&](hipStream_t s) { k_ntt_col_r<3, INV, true><<<dim3(r2 / 32, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack); });
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
+                    k_ntt_col_r<3, INV, decltype(ar)::value>
+                        <<<dim3(r2 / 32, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack);
+                }); },
+                [&](hipStream_t s) { k_ntt_col_r<3, INV, AR_FP><<<dim3(r2 / 32, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack); });
             break;
         case 2:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_col_r<2, INV, decltype(ar)::value><<<dim3(r2 / 64, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack); }); },
-                [&](hipStream_t s) { k_ntt_col_r<2, INV, true><<<dim3(r2 / 64, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack); });
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
+                    k_ntt_col_r<2, INV, decltype(ar)::value>
+                        <<<dim3(r2 / 64, items), NTT_THREADS, 0, s>>>(io, T, scale, scale_sh, pack);
+                }); },
+                [&](hipStream_t s) { k_ntt_col_r<2, INV, AR_FP><<<dim3(r2 / 64, itemsf), NTT_THREADS, 0, s>>>(iof, T, scale, scale_sh, pack); });
             break;
         default:
             if (pack) throw std::logic_error("packed output needs the radix column kernel");
@@ -866,23 +875,35 @@ static void launch_row(const NttIo &io0, const NttTables &T, uint32_t n_polys, c
     switch (fast_row(T.log_r2, r1)) {
         case 9:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_row3<INV, decltype(ar)::value><<<dim3((r1 / 4) * items), NTT_THREADS, 0, s>>>(io, T, tail); }); },
-                [&](hipStream_t s) { k_ntt_row3<INV, true><<<dim3((r1 / 4) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
+                    k_ntt_row3<INV, decltype(ar)::value>
+                        <<<dim3((r1 / 4) * items), NTT_THREADS, 0, s>>>(io, T, tail);
+                }); },
+                [&](hipStream_t s) { k_ntt_row3<INV, AR_FP><<<dim3((r1 / 4) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
             break;
         case 4:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_row_r<4, INV, decltype(ar)::value><<<dim3((r1 / 16) * items), NTT_THREADS, 0, s>>>(io, T, tail); }); },
-                [&](hipStream_t s) { k_ntt_row_r<4, INV, true><<<dim3((r1 / 16) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
+                    k_ntt_row_r<4, INV, decltype(ar)::value>
+                        <<<dim3((r1 / 16) * items), NTT_THREADS, 0, s>>>(io, T, tail);
+                }); },
+                [&](hipStream_t s) { k_ntt_row_r<4, INV, AR_FP><<<dim3((r1 / 16) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
             break;
         case 3:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_row_r<3, INV, decltype(ar)::value><<<dim3((r1 / 32) * items), NTT_THREADS, 0, s>>>(io, T, tail); }); },
-                [&](hipStream_t s) { k_ntt_row_r<3, INV, true><<<dim3((r1 / 32) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
+                    k_ntt_row_r<3, INV, decltype(ar)::value>
+                        <<<dim3((r1 / 32) * items), NTT_THREADS, 0, s>>>(io, T, tail);
+                }); },
+                [&](hipStream_t s) { k_ntt_row_r<3, INV, AR_FP><<<dim3((r1 / 32) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
             break;
         case 2:
             launch_two_classes(ln, items != 0, itemsf != 0,
-                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_ntt_row_r<2, INV, decltype(ar)::value><<<dim3((r1 / 64) * items), NTT_THREADS, 0, s>>>(io, T, tail); }); },
-                [&](hipStream_t s) { k_ntt_row_r<2, INV, true><<<dim3((r1 / 64) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
+                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
+                    k_ntt_row_r<2, INV, decltype(ar)::value>
+                        <<<dim3((r1 / 64) * items), NTT_THREADS, 0, s>>>(io, T, tail);
+                }); },
+                [&](hipStream_t s) { k_ntt_row_r<2, INV, AR_FP><<<dim3((r1 / 64) * itemsf), NTT_THREADS, 0, s>>>(iof, T, tail); });
             break;
         default: {
             if (tail.enabled) throw std::logic_error("fused tail needs the radix row kernel");
@@ -918,8 +939,11 @@ template <int LOG_H, int N_IN, int SRCMODE>
 static void launch_conv_col_n(const ConvIo &io, const ConvIo &iof, const dim3 &grid, const dim3 &gridf, const NttTables &T,
                               const DevConv &cv, const Lanes &ln) {
     launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
-        [&](hipStream_t s) { with_int_arith(T, [&](auto ar) { k_conv_col<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE><<<grid, NTT_THREADS, 0, s>>>(io, T, cv); }); },
-        [&](hipStream_t s) { k_conv_col<LOG_H, N_IN, true, DevConv, SRCMODE><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
+        [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
+            k_conv_col<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE>
+                <<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
+        }); },
+        [&](hipStream_t s) { k_conv_col<LOG_H, N_IN, AR_FP, DevConv, SRCMODE><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
 }
 template <int LOG_H, int N_IN>
 static void launch_conv_col_m(const ConvIo &io, const ConvIo &iof, const dim3 &grid, const dim3 &gridf, const NttTables &T,
@@ -964,8 +988,11 @@ template <int LOG_H, int N_IN>
 static void launch_conv_col_sum_n(const ConvIo &io, const ConvIo &iof, uint32_t tiles, const NttTables &T, const DevConv &cv,
                                   hipStream_t s, hipStream_t s_int) {
     // the integer-class instance (one target, q_0: a few hundred long-running workgroups) beside the fp64 one
-    if (io.nsel) with_int_arith(T, [&](auto ar) { k_conv_col_sum<LOG_H, N_IN, decltype(ar)::value, DevConv><<<dim3(io.items * tiles * io.nsel), NTT_THREADS, 0, s_int>>>(io, T, cv); });
-    if (iof.nsel) k_conv_col_sum<LOG_H, N_IN, true, DevConv><<<dim3(iof.items * tiles * iof.nsel), NTT_THREADS, 0, s>>>(iof, T, cv);
+    if (io.nsel) with_int_arith(T, [&](auto ar) {
+        k_conv_col_sum<LOG_H, N_IN, decltype(ar)::value, DevConv>
+            <<<dim3(io.items * tiles * io.nsel), NTT_THREADS, 0, s_int>>>(io, T, cv);
+    });
+    if (iof.nsel) k_conv_col_sum<LOG_H, N_IN, AR_FP, DevConv><<<dim3(iof.items * tiles * iof.nsel), NTT_THREADS, 0, s>>>(iof, T, cv);
 }
 template <int LOG_H>
 static void launch_conv_col_sum_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, hipStream_t s, hipStream_t s_int) {
@@ -1086,8 +1113,11 @@ static void launch_switch_col(const u64 *last, u64 *out, const NttTables &T, uin
     for (uint32_t i = 0; i < n_targets; ++i) (T.h_fp_of[i] ? mf : mi) |= 1ull << i;
     const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
     const uint32_t ni = (uint32_t)__builtin_popcountll(mi), nf = (uint32_t)__builtin_popcountll(mf);
-    if (ni) with_int_arith(T, [&](auto ar) { k_switch_col<LOG_H, decltype(ar)::value><<<dim3(tiles, ni, items), NTT_THREADS, 0, s>>>(last, out, T, n_targets, q_last, mi); });
-    if (nf) k_switch_col<LOG_H, true><<<dim3(tiles, nf, items), NTT_THREADS, 0, s>>>(last, out, T, n_targets, q_last, mf);
+    if (ni) with_int_arith(T, [&](auto ar) {
+        k_switch_col<LOG_H, decltype(ar)::value>
+            <<<dim3(tiles, ni, items), NTT_THREADS, 0, s>>>(last, out, T, n_targets, q_last, mi);
+    });
+    if (nf) k_switch_col<LOG_H, AR_FP><<<dim3(tiles, nf, items), NTT_THREADS, 0, s>>>(last, out, T, n_targets, q_last, mf);
 }
 
 void Engine::rescale(const u64 *in, u64 *out, uint32_t n_ct, uint32_t nl, const std::vector<u64> *factors) {
@@ -1382,12 +1412,30 @@ static void launch_row3_inner_int_k(const InnerArgs &a, const NttTables &T, uint
     if (!a.nsel) return;
     const dim3 grid(((1u << T.log_r1) / RowT<LOGC>::ROWS) * a.nsel * a.items);
     switch (nparts) {
-        case 1: with_int_arith(T, [&](auto ar) { k_row3_inner_int<1, LOGC, INVP, decltype(ar)::value><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); }); break;
-        case 2: with_int_arith(T, [&](auto ar) { k_row3_inner_int<2, LOGC, INVP, decltype(ar)::value><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); }); break;
-        case 3: with_int_arith(T, [&](auto ar) { k_row3_inner_int<3, LOGC, INVP, decltype(ar)::value><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); }); break;
-        case 4: with_int_arith(T, [&](auto ar) { k_row3_inner_int<4, LOGC, INVP, decltype(ar)::value><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); }); break;
-        case 5: with_int_arith(T, [&](auto ar) { k_row3_inner_int<5, LOGC, INVP, decltype(ar)::value><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); }); break;
-        case 6: with_int_arith(T, [&](auto ar) { k_row3_inner_int<6, LOGC, INVP, decltype(ar)::value><<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K); }); break;
+        case 1: with_int_arith(T, [&](auto ar) {
+            k_row3_inner_int<1, LOGC, INVP, decltype(ar)::value>
+                <<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K);
+        }); break;
+        case 2: with_int_arith(T, [&](auto ar) {
+            k_row3_inner_int<2, LOGC, INVP, decltype(ar)::value>
+                <<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K);
+        }); break;
+        case 3: with_int_arith(T, [&](auto ar) {
+            k_row3_inner_int<3, LOGC, INVP, decltype(ar)::value>
+                <<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K);
+        }); break;
+        case 4: with_int_arith(T, [&](auto ar) {
+            k_row3_inner_int<4, LOGC, INVP, decltype(ar)::value>
+                <<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K);
+        }); break;
+        case 5: with_int_arith(T, [&](auto ar) {
+            k_row3_inner_int<5, LOGC, INVP, decltype(ar)::value>
+                <<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K);
+        }); break;
+        case 6: with_int_arith(T, [&](auto ar) {
+            k_row3_inner_int<6, LOGC, INVP, decltype(ar)::value>
+                <<<grid, NTT_THREADS, 0, s>>>(a, T, L, pc, K);
+        }); break;
         default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
     }
 }
@@ -1487,8 +1535,11 @@ static void launch_row3_tail_sum(SumArgs a, const NttTables &T, hipStream_t s, u
     for (uint32_t i = 0; i < a.nl; ++i) (T.h_fp_of[i] ? af.slot_mask : ai.slot_mask) |= 1ull << i;
     ai.nsel = (uint32_t)__builtin_popcountll(ai.slot_mask);
     af.nsel = (uint32_t)__builtin_popcountll(af.slot_mask);
-    if (ai.nsel && (classes & 1)) with_int_arith(T, [&](auto ar) { k_row3_tail_sum<decltype(ar)::value, LOGC><<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s>>>(ai, T); });
-    if (af.nsel && (classes & 2)) k_row3_tail_sum<true, LOGC><<<dim3(tiles * af.nsel * a.n_polys), NTT_THREADS, 0, s>>>(af, T);
+    if (ai.nsel && (classes & 1)) with_int_arith(T, [&](auto ar) {
+        k_row3_tail_sum<decltype(ar)::value, LOGC>
+            <<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s>>>(ai, T);
+    });
+    if (af.nsel && (classes & 2)) k_row3_tail_sum<AR_FP, LOGC><<<dim3(tiles * af.nsel * a.n_polys), NTT_THREADS, 0, s>>>(af, T);
 }
 
 template <int LOG_H>
@@ -1505,12 +1556,18 @@ static void launch_row_tail_sum(SumArgs a, const NttTables &T, bool pair, hipStr
     // two clients per workgroup iteration (shared twiddle fetches, two dependency chains): the default; 2 waves per
     // SIMD either way (212 VGPRs, no spills; measured equal to 3 waves, faster than 4)
     if (pair && LOG_H == 4) {
-        if (ai.nsel) with_int_arith(T, [&](auto ar) { k_row_tail_sum2<LOG_H, decltype(ar)::value><<<gi, NTT_THREADS, 0, s>>>(ai, T); });
-        if (af.nsel) k_row_tail_sum2<LOG_H, true><<<gf, NTT_THREADS, 0, s>>>(af, T);
+        if (ai.nsel) with_int_arith(T, [&](auto ar) {
+            k_row_tail_sum2<LOG_H, decltype(ar)::value>
+                <<<gi, NTT_THREADS, 0, s>>>(ai, T);
+        });
+        if (af.nsel) k_row_tail_sum2<LOG_H, AR_FP><<<gf, NTT_THREADS, 0, s>>>(af, T);
     } else {
         if (a.til_compact) throw std::logic_error("compact accumulators need the paired sum kernel");
-        if (ai.nsel) with_int_arith(T, [&](auto ar) { k_row_tail_sum<LOG_H, decltype(ar)::value, 2><<<gi, NTT_THREADS, 0, s>>>(ai, T); });
-        if (af.nsel) k_row_tail_sum<LOG_H, true, 2><<<gf, NTT_THREADS, 0, s>>>(af, T);
+        if (ai.nsel) with_int_arith(T, [&](auto ar) {
+            k_row_tail_sum<LOG_H, decltype(ar)::value, 2>
+                <<<gi, NTT_THREADS, 0, s>>>(ai, T);
+        });
+        if (af.nsel) k_row_tail_sum<LOG_H, AR_FP, 2><<<gf, NTT_THREADS, 0, s>>>(af, T);
     }
 }
 
@@ -1666,8 +1723,14 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
                                 g0 != 0 ? 1u : 0u};
                 const uint32_t tiles = (1u << tabs_.log_r1) / (wide_rows ? RowT<3>::ROWS : RowT<2>::ROWS);
                 const dim3 grid(tiles * n_intq * 2 * cnt);
-                if (wide_rows) with_int_arith(tabs_, [&](auto ar) { k_row3_tail_once<3, decltype(ar)::value><<<grid, NTT_THREADS, 0, main>>>(ta, tabs_); });
-                else with_int_arith(tabs_, [&](auto ar) { k_row3_tail_once<2, decltype(ar)::value><<<grid, NTT_THREADS, 0, main>>>(ta, tabs_); });
+                if (wide_rows) with_int_arith(tabs_, [&](auto ar) {
+                    k_row3_tail_once<3, decltype(ar)::value>
+                        <<<grid, NTT_THREADS, 0, main>>>(ta, tabs_);
+                });
+                else with_int_arith(tabs_, [&](auto ar) {
+                    k_row3_tail_once<2, decltype(ar)::value>
+                        <<<grid, NTT_THREADS, 0, main>>>(ta, tabs_);
+                });
             }
             QSumArgs qa{dig, convsum, ct0, evk0, out + (size_t)b0 * ct_words, pq, ct_cstride, ct_words, evk_words, ct_words,
                         gc, cnt, nl, ext, D, ps_.alpha, fp_mask, (uint32_t)__builtin_popcountll(fp_mask), g0 != 0 ? 1u : 0u};

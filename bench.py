@@ -290,15 +290,25 @@ def main():
     def make_comm(cx):
         if not exchange or backend != "nccl" or os.environ.get("MKCKKS_BENCH_TORCH_COLLECTIVE") == "1":
             return None
+        comm, err = None, ""
         try:
             uid = torch.zeros(128, dtype=torch.uint8, device=dev)
             if rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(cx.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(uid, 0)
-            return cx.comm_create(bytes(uid.cpu().numpy().tobytes()), world, rank)
+            comm = cx.comm_create(bytes(uid.cpu().numpy().tobytes()), world, rank)
         except Exception as e:  # keep the job alive on the torch.distributed collective
-            log(f"[bench] C-ABI communicator unavailable ({e}); using torch.distributed reduce_scatter")
+            err = str(e)
+        # every rank must take the same route: one rank without a communicator sends all of them to torch.distributed
+        ok = torch.tensor([1 if comm is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok) != 1:
+            if comm is not None:
+                cx.comm_destroy(comm)
+            log(f"[bench] C-ABI communicator unavailable on some rank ({err or 'see the other ranks'}); "
+                "using torch.distributed reduce_scatter")
             return None
+        return comm
 
     def exchange_step(cx, partial, shard_out):
         comm = comms.get(id(cx))

@@ -72,12 +72,15 @@ def usable_cores():
 
 
 def cpu_baseline(args, log):
-    """The oracle (CPU restatement, OpenMP over limbs like OpenFHE's WITH_OPENMP build) on a bounded sample of
-    the same workload: `pre` ciphertexts PRE'd, summed, one rescale*const.  kind = "port".  Timed twice: with ONE
-    thread and with every core this process may use; `value` is the all-core number."""
-    from oracle.oracle import OracleContext, set_threads
+    """The CPU port (OpenMP over limbs like OpenFHE's WITH_OPENMP build) on a bounded sample of the same workload: `pre`
+    ciphertexts PRE'd, summed, one rescale*const.  kind = "port".  ReEncrypt -- all of the work but one rescale per
+    sample -- runs through oracle/cpu_fast.c: the restatement's algorithm carried out the way OpenFHE's native backend
+    does (lazy Shoup butterflies, Barrett / Shoup constants, tables built once), word for word equal to the restatement
+    (tests/test_oracle_algebra.py) and about twice as fast.  Timed twice: with ONE thread and with every core this
+    process may use; `value` is the all-core number."""
+    from oracle.oracle import FastCpuContext, set_threads
     t0 = time.time()
-    o = OracleContext(args.log_n, args.depth, args.scaling_bits, 60, dnum=args.dnum)
+    o = FastCpuContext(args.log_n, args.depth, args.scaling_bits, 60, dnum=args.dnum)
     log(f"[cpu] oracle context built in {time.time() - t0:.1f}s")
     rng = np.random.default_rng(1)
     N, L, D = o.N, o.L, o.D
@@ -125,8 +128,10 @@ def cpu_baseline(args, log):
             "host_cores_visible": os.cpu_count(), "cores_usable": usable_cores(),
             "threads_1": {"value": v1, "cores": 1, "sample_ciphertexts": max(2, args.cpu_sample // 48), "seconds": dt1},
             "threads_all": {"value": va, "cores": n_all, "sample_ciphertexts": args.cpu_sample, "seconds": dta},
+            "implementation": "oracle/cpu_fast.c (scalar C, 128-bit products, lazy Shoup butterflies; bit-equal to the "
+                              "restatement oracle/mkckks_oracle.c, which is ~2x slower)",
             "sample": f"{args.cpu_sample} ciphertexts PRE'd + summed + 1 rescale*const at N=2^{args.log_n}, L={L}, "
-                      f"dnum={args.dnum}; oracle/liboracle.so (OpenMP over <= 2L limbs), all-core leg {dta:.1f}s, "
+                      f"dnum={args.dnum}; oracle/libcpufast.so (OpenMP over <= 2L limbs), all-core leg {dta:.1f}s, "
                       f"1-thread leg {dt1:.1f}s on {max(2, args.cpu_sample // 48)} ciphertexts"}
 
 

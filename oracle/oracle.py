@@ -14,22 +14,27 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, os.environ.get("ORACLE_LIB", "liboracle.so"))  # ORACLE_LIB: the sanitizer build
 
 
+_FAST_PATH = os.path.join(_HERE, "libcpufast.so")  # cpu_fast.c: the restatement + a faster ReEncrypt (bench's CPU leg)
+
+
 def build(force=False):
-    src = os.path.join(_HERE, "mkckks_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("mkckks_oracle.c", "cpu_fast.c")]
+    stale = any(not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(x) for x in srcs)
+                for o in (_LIB_PATH, _FAST_PATH))
+    if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+def lib(path=None):
+    path = path or _LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
             build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(path)
         u32, u64, dbl, vp = C.c_uint32, C.c_uint64, C.c_double, C.c_void_p
         L.orc_ctx_new.restype = vp
         L.orc_ctx_new.argtypes = [u32] * 7
@@ -63,15 +68,19 @@ def lib():
         L.orc_encrypt.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
         L.orc_decrypt_decode.argtypes = [vp, u32, vp, vp, dbl, vp]
         L.orc_decrypt_core.argtypes = [vp, u32, vp, vp, vp]
-        _lib = L
-    return _lib
+        if hasattr(L, "fcpu_reencrypt"):
+            L.fcpu_reencrypt.argtypes = [vp, u32, vp, vp, vp]
+            L.fcpu_ntt_fwd.argtypes = [vp, u32, vp]
+            L.fcpu_ntt_inv.argtypes = [vp, u32, vp]
+        _libs[path] = L
+    return _libs[path]
 
 
 def set_threads(n):
     """Cap the OpenMP team of the restatement (bench.py's cpu_baseline states the count it used)."""
-    L = lib()
-    L.orc_set_threads.argtypes = [C.c_int]
-    L.orc_set_threads(int(n))
+    for L in [lib()] + [v for k, v in _libs.items() if k != _LIB_PATH]:  # each library carries its own OpenMP state
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads(int(n))
 
 
 def _p(a):
@@ -86,8 +95,10 @@ def _u64(a):
 class OracleContext:
     """CKKS context with OpenFHE's FLEXIBLEAUTOEXT/HYBRID parameter selection."""
 
+    _lib_path = None  # the restatement; FastCpuContext points at libcpufast.so
+
     def __init__(self, log_n, mult_depth, scaling_bits, first_bits=60, dnum=3, aux_bits=60, extra_bits=20):
-        self.L_ = lib()
+        self.L_ = lib(self._lib_path)
         self.h = self.L_.orc_ctx_new(log_n, mult_depth, scaling_bits, first_bits, dnum, aux_bits, extra_bits)
         self.N = self.L_.orc_ring_dim(self.h)
         self.L = self.L_.orc_num_q(self.h)
@@ -228,6 +239,31 @@ class OracleContext:
 
 
 # ---- seeded samplers shared by tests and bench (numpy; not part of the product)
+
+class FastCpuContext(OracleContext):
+    """The same context out of libcpufast.so (cpu_fast.c = the restatement + fcpu_reencrypt): ReEncrypt the way OpenFHE's
+    native backend carries it out (lazy butterflies, Shoup/Barrett constants, tables built once).  bench.py's cpu_baseline
+    times this one; tests compare it with OracleContext.reencrypt word for word."""
+    _lib_path = _FAST_PATH
+
+    def reencrypt(self, ct, evk):
+        ct, evk = _u64(ct), _u64(evk)
+        nl = ct.shape[1]
+        assert evk.shape == (self.beta, 2, self.D, self.N)
+        out = np.empty_like(ct)
+        self.L_.fcpu_reencrypt(self.h, nl, _p(ct), _p(evk), _p(out))
+        return out
+
+    def ntt_fwd(self, limb, a):
+        a = _u64(a).copy()
+        self.L_.fcpu_ntt_fwd(self.h, limb, _p(a))
+        return a
+
+    def ntt_inv(self, limb, a):
+        a = _u64(a).copy()
+        self.L_.fcpu_ntt_inv(self.h, limb, _p(a))
+        return a
+
 
 def sample_ternary(rng, n):
     """[upstream] TernaryUniformGeneratorImpl: uniform over {-1,0,1}."""

@@ -175,3 +175,30 @@ def test_reencrypt_noise_and_levels(small_ctx, nl_drop):
         assert max(abs(int(x)) for x in d) < 2 ** 14, "key-switch noise must stay small"
     dec = ctx.decrypt_decode(out, sk2, scale)
     assert np.abs(dec - vals).max() < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [(10, 3, 40, 60, 2), (14, 2, 40, 60, 2), (12, 18, 50, 60, 3), (14, 2, 40, 55, 2)])
+def test_fast_cpu_reencrypt_equals_the_restatement(cfg):
+    """oracle/cpu_fast.c (what bench.py's cpu_baseline leg times) carries out the restatement's ReEncrypt with lazy
+    butterflies and precomputed constants: every output word must equal orc_reencrypt's, at full level, after dropped
+    limbs, with a partial last digit and with a single limb; and its transforms must equal the restatement's."""
+    from oracle.oracle import FastCpuContext, OracleContext
+    o = OracleContext(*cfg[:4], dnum=cfg[4])
+    f = FastCpuContext(*cfg[:4], dnum=cfg[4])
+    assert np.array_equal(o.moduli, f.moduli)
+    rng = np.random.default_rng(5)
+    evk = np.empty((o.beta, 2, o.D, o.N), dtype=np.uint64)
+    for l in range(o.D):
+        evk[:, :, l, :] = rng.integers(0, int(o.moduli[l]), (o.beta, 2, o.N), dtype=np.uint64)
+    for nl in sorted({o.L, o.L - 1, o.alpha + 1, 2, 1}):
+        if not 1 <= nl <= o.L:
+            continue
+        ct = np.stack([np.stack([rng.integers(0, int(o.moduli[l]), o.N, dtype=np.uint64) for l in range(nl)])
+                       for _ in range(2)])
+        ct[0, 0, ::3] = int(o.moduli[0]) - 1  # boundary residues
+        assert np.array_equal(o.reencrypt(ct, evk), f.reencrypt(ct, evk)), (cfg, nl)
+    for limb in (0, o.L - 1, o.D - 1):
+        x = rng.integers(0, int(o.moduli[limb]), o.N, dtype=np.uint64)
+        x[:4] = int(o.moduli[limb]) - 1
+        assert np.array_equal(o.ntt_fwd(limb, x), f.ntt_fwd(limb, x))
+        assert np.array_equal(o.ntt_inv(limb, x), f.ntt_inv(limb, x))

@@ -198,7 +198,8 @@ def main():
     ap.add_argument("--dnum", type=int, default=3)
     ap.add_argument("--clients", type=int, default=8, help="clients per GPU")
     ap.add_argument("--cts", type=int, default=16, help="ciphertexts per client (multiple of --gpus)")
-    ap.add_argument("--cpu-sample", type=int, default=384, help="ciphertexts in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=1536,
+                    help="ciphertexts in the CPU-baseline sample (about 17 s on 16 cores; the 1-thread leg takes 1/48 of it)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--verify", action="store_true",
                     help="N>1 only, after the timed region: check the integer reduce-scatter + reduce_mod + rescale "

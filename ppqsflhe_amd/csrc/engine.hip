@@ -486,6 +486,7 @@ Knobs Knobs::from_env() {
     }
     k.generic_ntt = env_flag("MKCKKS_GENERIC_NTT", k.generic_ntt);
     k.no_pm = env_flag("MKCKKS_NO_PM", k.no_pm);
+    k.conv_pairs = env_flag("MKCKKS_CONV_PAIRS", k.conv_pairs);
     k.no_fp64 = env_flag("MKCKKS_NO_FP64", k.no_fp64);
     k.fuse_inner = env_flag("MKCKKS_FUSE_INNER", k.fuse_inner);
     k.fuse_inner_int = env_flag("MKCKKS_FUSE_INNER_INT", k.fuse_inner_int);
@@ -986,16 +987,28 @@ static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevCo
 // io.items = polynomials per client
 template <int LOG_H, int N_IN>
 static void launch_conv_col_sum_n(const ConvIo &io, const ConvIo &iof, uint32_t tiles, const NttTables &T, const DevConv &cv,
-                                  hipStream_t s, hipStream_t s_int) {
+                                  hipStream_t s, hipStream_t s_int, bool pair_targets) {
     // the integer-class instance (one target, q_0: a few hundred long-running workgroups) beside the fp64 one
     if (io.nsel) with_int_arith(T, [&](auto ar) {
         k_conv_col_sum<LOG_H, N_IN, decltype(ar)::value, DevConv>
             <<<dim3(io.items * tiles * io.nsel), NTT_THREADS, 0, s_int>>>(io, T, cv);
     });
-    if (iof.nsel) k_conv_col_sum<LOG_H, N_IN, AR_FP, DevConv><<<dim3(iof.items * tiles * iof.nsel), NTT_THREADS, 0, s>>>(iof, T, cv);
+    if (iof.nsel) {
+        if constexpr (N_IN <= 4) {
+            if (pair_targets) {  // two fp64 targets per workgroup: half the source traffic through L2
+                k_conv_col_sum2<LOG_H, N_IN, DevConv>
+                    <<<dim3(iof.items * tiles * ((iof.nsel + 1) / 2)), NTT_THREADS, 0, s>>>(iof, T, cv);
+                return;
+            }
+        }
+        {
+            k_conv_col_sum<LOG_H, N_IN, AR_FP, DevConv><<<dim3(iof.items * tiles * iof.nsel), NTT_THREADS, 0, s>>>(iof, T, cv);
+        }
+    }
 }
 template <int LOG_H>
-static void launch_conv_col_sum_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, hipStream_t s, hipStream_t s_int) {
+static void launch_conv_col_sum_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, hipStream_t s, hipStream_t s_int,
+                                  bool pair_targets) {
     const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
     ConvIo io = io0, iof = io0;
     io.target_mask = iof.target_mask = 0;
@@ -1003,21 +1016,22 @@ static void launch_conv_col_sum_h(const ConvIo &io0, const NttTables &T, const D
     io.nsel = (uint32_t)__builtin_popcountll(io.target_mask);
     iof.nsel = (uint32_t)__builtin_popcountll(iof.target_mask);
     switch (cv.n_in) {
-        case 1: launch_conv_col_sum_n<LOG_H, 1>(io, iof, tiles, T, cv, s, s_int); break;
-        case 2: launch_conv_col_sum_n<LOG_H, 2>(io, iof, tiles, T, cv, s, s_int); break;
-        case 3: launch_conv_col_sum_n<LOG_H, 3>(io, iof, tiles, T, cv, s, s_int); break;
-        case 4: launch_conv_col_sum_n<LOG_H, 4>(io, iof, tiles, T, cv, s, s_int); break;
-        case 5: launch_conv_col_sum_n<LOG_H, 5>(io, iof, tiles, T, cv, s, s_int); break;
-        case 6: launch_conv_col_sum_n<LOG_H, 6>(io, iof, tiles, T, cv, s, s_int); break;
-        case 7: launch_conv_col_sum_n<LOG_H, 7>(io, iof, tiles, T, cv, s, s_int); break;
-        case 8: launch_conv_col_sum_n<LOG_H, 8>(io, iof, tiles, T, cv, s, s_int); break;
+        case 1: launch_conv_col_sum_n<LOG_H, 1>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
+        case 2: launch_conv_col_sum_n<LOG_H, 2>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
+        case 3: launch_conv_col_sum_n<LOG_H, 3>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
+        case 4: launch_conv_col_sum_n<LOG_H, 4>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
+        case 5: launch_conv_col_sum_n<LOG_H, 5>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
+        case 6: launch_conv_col_sum_n<LOG_H, 6>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
+        case 7: launch_conv_col_sum_n<LOG_H, 7>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
+        case 8: launch_conv_col_sum_n<LOG_H, 8>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
         default: throw std::invalid_argument("base conversion fan-in unsupported");
     }
 }
-static void launch_conv_col_sum(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s, hipStream_t s_int) {
+static void launch_conv_col_sum(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s, hipStream_t s_int,
+                                bool pair_targets) {
     switch (fast_log_h(T.log_r1, 1u << T.log_r2)) {
-        case 4: launch_conv_col_sum_h<4>(io, T, cv, s, s_int); break;
-        case 3: launch_conv_col_sum_h<3>(io, T, cv, s, s_int); break;
+        case 4: launch_conv_col_sum_h<4>(io, T, cv, s, s_int, pair_targets); break;
+        case 3: launch_conv_col_sum_h<3>(io, T, cv, s, s_int, pair_targets); break;
         default: throw std::logic_error("summed conversion needs 64- or 256-point columns");
     }
     MK_HIP(hipGetLastError());
@@ -1702,7 +1716,7 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
                     MK_HIP(hipEventRecord(ev_fork_, main));
                     MK_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
                 }
-                launch_conv_col_sum(cs, tabs_, cv, main, fork ? side_stream_ : main);
+                launch_conv_col_sum(cs, tabs_, cv, main, fork ? side_stream_ : main, knobs_.conv_pairs);
                 if (fork) {
                     MK_HIP(hipEventRecord(ev_join_, side_stream_));
                     MK_HIP(hipStreamWaitEvent(main, ev_join_, 0));

@@ -635,6 +635,76 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_sum(ConvIo io, NttT
     col_forward_finish<LOG_H, AR>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
 }
 
+// k_conv_col_sum for TWO fp64-class targets per workgroup.  The source tiles are the same for every target limb: with one
+// target per workgroup the 12 targets pull the 512 MiB of P limbs of a step through L2 twelve times (6 GiB at the
+// 8-byte-access rate -- about the duration of that kernel); forming two conversions from one load halves it.  Two sets of
+// running sums: 3 waves per SIMD instead of 4; the two column passes run one after the other.  The last group of an odd
+// target count carries one live target.
+template <int LOG_H, int N_IN, typename CONV>
+__global__ __launch_bounds__(NTT_THREADS, 3) void k_conv_col_sum2(ConvIo io, NttTables T, CONV cv) {
+    using TL = ColTile<LOG_H>;
+    constexpr int H = TL::H, S = TL::S, NT = 2;
+    static_assert(N_IN <= 4, "target pairs: at most 4 sources (plain three-column accumulation)");
+    __shared__ u64 lds[TL::WORDS];
+    const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
+    const uint32_t groups = io.items * tiles, ntg = (io.nsel + NT - 1) / NT;
+    uint32_t grp, jg;
+    if (groups % 8 == 0) {  // the target groups of one source tile: neighbours in one XCD's queue (see k_conv_col)
+        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
+        grp = (qidx / ntg) * 8 + xcd;
+        jg = qidx % ntg;
+    } else {
+        grp = blockIdx.x / ntg;
+        jg = blockIdx.x % ntg;
+    }
+    const uint32_t item = grp / tiles, tile = grp % tiles;
+    const bool two = jg * NT + 1 < io.nsel;  // workgroup-uniform
+    const uint32_t jta = nth_set_bit(io.target_mask, jg * NT), jtb = two ? nth_set_bit(io.target_mask, jg * NT + 1) : jta;
+    const uint32_t ida = cv.dst_id[jta], idb = cv.dst_id[jtb];
+    const LimbConst la = T.limb[ida], lb = T.limb[idb];
+    if (!la.fp || !lb.fp) return;  // never: the host selects fp64-class targets
+    const int c = threadIdx.x % S, j = threadIdx.x / S;
+    const u64 *src0 = io.in + (size_t)item * io.in_stride + tile * S + c;
+    uint32_t a0[N_IN], a1[N_IN], b0[N_IN], b1[N_IN];
+#pragma unroll
+    for (int i = 0; i < N_IN; ++i) {
+        split30(cv.hat[i * cv.n_out + jta], a0[i], a1[i]);
+        split30(cv.hat[i * cv.n_out + jtb], b0[i], b1[i]);
+    }
+    double sa[H], sb[H];  // exact doubles below 0.51 q + 4 q
+#pragma unroll
+    for (int k = 0; k < H; ++k) sa[k] = sb[k] = 0.0;
+#pragma unroll 1
+    for (uint32_t cl = 0; cl < io.n_clients; ++cl) {
+        const u64 *src = src0 + (size_t)cl * io.in_cstride;
+        uint32_t r2v = r2, nv = n;  // opaque per iteration: see k_conv_col_sum
+        asm volatile("" : "+s"(r2v), "+s"(nv));
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            Cols ca{0, 0, 0}, cb{0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < N_IN; ++i) {
+                const u64 p = src[cv.src_slot[i] * nv + (uint32_t)(j + H * k) * r2v];
+                mac_cols(ca, (uint32_t)p, (uint32_t)(p >> 32), a0[i], a1[i]);
+                mac_cols(cb, (uint32_t)p, (uint32_t)(p >> 32), b0[i], b1[i]);
+            }
+            sa[k] = fp_reduce(sa[k] + (double)reduce_cols_lazy(ca, la), la.qd, la.qinv);
+            sb[k] = fp_reduce(sb[k] + (double)reduce_cols_lazy(cb, lb), lb.qd, lb.qinv);
+        }
+    }
+    u64 x[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) x[k] = dbits(sa[k]);
+    u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jta] * n + tile * S + c;
+    col_forward_finish<LOG_H, AR_FP>(x, lds, T.tw + (size_t)ida * n, T.tw_sh + (size_t)ida * n, la, j, c, dst, r2);
+    if (!two) return;
+    __syncthreads();  // the first target's exchange is read out
+#pragma unroll
+    for (int k = 0; k < H; ++k) x[k] = dbits(sb[k]);
+    dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jtb] * n + tile * S + c;
+    col_forward_finish<LOG_H, AR_FP>(x, lds, T.tw + (size_t)idb * n, T.tw_sh + (size_t)idb * n, lb, j, c, dst, r2);
+}
+
 // DropLastElementAndScale, first half fused: NativeVectorT::SwitchModulus of the dropped limb (COEFFICIENT format,
 // canonical; centred lift: v > floor(q_last / 2) is negative) into a remaining limb + the forward column pass of that
 // limb -- the switched polynomial never goes to HBM in coefficient form.  last: [items][N]; out: [items][nl-1][N]

@@ -480,6 +480,7 @@ def test_reencrypt_sum(ctxs, name, nl, C, B):
                                  {"MKCKKS_SUM_ONE_LANE": "1"},    # clients strictly one after the other
                                  {"MKCKKS_NO_PM": "1"},           # Shoup butterflies on q_0 and the P limbs
                                  {"MKCKKS_NO_PM": "1", "MKCKKS_QSUM": "0"},
+                                 {"MKCKKS_CONV_PAIRS": "0"},      # one target limb per workgroup in the summed ModDown conversion
                                  {"MKCKKS_QSUM_GEOM": "4"},       # three-round k_qsum3_fp at 2 waves per SIMD
                                  {"MKCKKS_NO_FP64": "1"},         # integer (Shoup) arithmetic on every limb
                                  {"MKCKKS_NO_FP64": "1", "MKCKKS_QSUM": "0"},

@@ -52,7 +52,7 @@ void need(bool ok, const char *what) {
 extern "C" {
 
 const char *mkckks_last_error(void) { return g_err.c_str(); }
-const char *mkckks_version(void) { return "mkckks-hip 0.1 (gfx950)"; }
+const char *mkckks_version(void) { return "mkckks-hip 0.2 (gfx950)"; }
 
 int mkckks_ctx_create(const mkckks_params *p, mkckks_ctx **out) {
     return guarded([&] {

@@ -487,7 +487,6 @@ Knobs Knobs::from_env() {
     k.generic_ntt = env_flag("MKCKKS_GENERIC_NTT", k.generic_ntt);
     k.no_pm = env_flag("MKCKKS_NO_PM", k.no_pm);
     k.conv_pairs = env_flag("MKCKKS_CONV_PAIRS", k.conv_pairs);
-    k.conv_halves = env_flag("MKCKKS_CONV_HALVES", k.conv_halves);
     k.no_fp64 = env_flag("MKCKKS_NO_FP64", k.no_fp64);
     k.fuse_inner = env_flag("MKCKKS_FUSE_INNER", k.fuse_inner);
     k.fuse_inner_int = env_flag("MKCKKS_FUSE_INNER_INT", k.fuse_inner_int);
@@ -940,21 +939,6 @@ static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inve
 template <int LOG_H, int N_IN, int SRCMODE>
 static void launch_conv_col_n(const ConvIo &io, const ConvIo &iof, const dim3 &grid, const dim3 &gridf, const NttTables &T,
                               const DevConv &cv, const Lanes &ln) {
-    if constexpr (N_IN <= 4 && LOG_H == 4) {
-        if (io.halves) {  // two targets per 512-thread workgroup: the second half's source loads hit L1
-            const uint32_t per_t = io.nsel ? grid.x / io.nsel : 0, per_tf = iof.nsel ? gridf.x / iof.nsel : 0;
-            const dim3 grid2(per_t * ((io.nsel + 1) / 2)), gridf2(per_tf * ((iof.nsel + 1) / 2));
-            launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
-                [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
-                    k_conv_col<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE, 2>
-                        <<<grid2, 2 * NTT_THREADS, 0, s>>>(io, T, cv);
-                }); },
-                [&](hipStream_t s) {
-                    k_conv_col<LOG_H, N_IN, AR_FP, DevConv, SRCMODE, 2><<<gridf2, 2 * NTT_THREADS, 0, s>>>(iof, T, cv);
-                });
-            return;
-        }
-    }
     launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
         [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
             k_conv_col<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE>
@@ -1276,7 +1260,6 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
     for (uint32_t part = 0; part < nparts && fused; ++part) {
         // S2+S3a: base conversion fused into the column pass of each complement limb
         ConvIo io{coef, dig + (size_t)part * ext * n, (size_t)nl * n, dstride, cnt, 0, 0};
-        io.halves = knobs_.conv_halves ? 1u : 0u;
         const DevConv &cv = modup_conv(nl, part);
         launch_conv_col(io, tabs_, cv, lanes(), doubles ? conv_src_mode(cv) : 0);
     }

@@ -442,7 +442,6 @@ struct ConvIo {
     // k_conv_col_sum: item i of client c is read at in + c * in_cstride + i * in_stride
     uint32_t n_clients = 1;
     size_t in_cstride = 0;
-    uint32_t halves = 0;  // HOST: launch k_conv_col with two targets per 512-thread workgroup (NH = 2)
 };
 // canonical integer below 2^52 held in a double -> its 30-bit halves (what split30 gives for the u64)
 MK_D void split30_d(u64 dbl_bits, uint32_t &lo, uint32_t &hi) {
@@ -456,43 +455,29 @@ template <int SRCMODE>
 MK_D constexpr bool src_is_double(int i) {
     return SRCMODE == 1 || (SRCMODE == 2 && i > 0);
 }
-// NH = 2: a workgroup of 512 threads whose two halves (waves 0-3 / 4-7) convert the SAME source tile into two different
-// target limbs.  Both halves run the same instruction stream a few cycles apart, so the second half's source loads hit
-// the lines the first half just brought into the CU's L1: the source traffic through L2 halves without a register (the
-// register-resident pairing of round 2 lost 6-11 % to spills).  Each half has its own exchange tile; same occupancy
-// (2 workgroups of 8 waves per CU instead of 4 of 4).
-template <int LOG_H, int N_IN, int AR, typename CONV, int SRCMODE = 0, int NH = 1>
-__global__ __launch_bounds__(NTT_THREADS * NH, 4) void k_conv_col(ConvIo io, NttTables T, CONV cv) {
+template <int LOG_H, int N_IN, int AR, typename CONV, int SRCMODE = 0>
+__global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTables T, CONV cv) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
     static_assert(SRCMODE == 0 || N_IN <= 4, "double sources: at most 4 per digit");
-    static_assert(NH == 1 || NH == 2, "one or two targets per workgroup");
-    __shared__ u64 lds_all[NH * TL::WORDS];
-    // wave-uniform: which half of the workgroup this wave belongs to (kept in a scalar register)
-    const uint32_t half = NH == 1 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / NTT_THREADS));
-    const int tid = (int)(threadIdx.x % NTT_THREADS);
-    u64 *lds = lds_all + half * TL::WORDS;
+    __shared__ u64 lds[TL::WORDS];
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
     const uint32_t groups = io.items * tiles;  // source tiles
-    const uint32_t ntg = (io.nsel + NH - 1) / NH;  // target groups per source tile
-    uint32_t grp, jg;
+    uint32_t grp, jt;
     if (groups % 8 == 0) {  // XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch)
         const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / ntg) * 8 + xcd;
-        jg = qidx % ntg;
+        grp = (qidx / io.nsel) * 8 + xcd;
+        jt = qidx % io.nsel;
     } else {
-        grp = blockIdx.x / ntg;
-        jg = blockIdx.x % ntg;
+        grp = blockIdx.x / io.nsel;
+        jt = blockIdx.x % io.nsel;
     }
-    // the last group of an odd target count: the second half repeats the first one's target and stores the same words a
-    // second time (a branch around its stores costs 20-70 registers in this kernel)
-    const bool live = jg * NH + half < io.nsel;
-    const uint32_t jt = nth_set_bit(io.target_mask, live ? jg * NH + half : jg * NH);
+    jt = nth_set_bit(io.target_mask, jt);
     const uint32_t item = grp / tiles, tile = grp % tiles;
     const uint32_t id = cv.dst_id[jt];
     const LimbConst lc = T.limb[id];
     if ((lc.fp != 0) != (AR == AR_FP)) return;  // block-uniform
-    const int c = tid % S, j = tid / S;
+    const int c = threadIdx.x % S, j = threadIdx.x / S;
     const u64 *src = io.in + (size_t)item * io.in_stride + tile * S + c;
     u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jt] * n + tile * S + c;
     u64 x[H];

@@ -486,7 +486,6 @@ Knobs Knobs::from_env() {
     }
     k.generic_ntt = env_flag("MKCKKS_GENERIC_NTT", k.generic_ntt);
     k.no_pm = env_flag("MKCKKS_NO_PM", k.no_pm);
-    k.conv_pairs = env_flag("MKCKKS_CONV_PAIRS", k.conv_pairs);
     k.no_fp64 = env_flag("MKCKKS_NO_FP64", k.no_fp64);
     k.fuse_inner = env_flag("MKCKKS_FUSE_INNER", k.fuse_inner);
     k.fuse_inner_int = env_flag("MKCKKS_FUSE_INNER_INT", k.fuse_inner_int);
@@ -983,32 +982,19 @@ static void launch_conv_col_h(const ConvIo &io0, const NttTables &T, const DevCo
         default: throw std::invalid_argument("base conversion fan-in unsupported");
     }
 }
-// ModDown conversion summed over clients (k_conv_col_sum), one instance per arithmetic class of the targets;
-// io.items = polynomials per client
+// the group's ONE ModDown conversion (k_conv_col_psum), one instance per arithmetic class of the targets
 template <int LOG_H, int N_IN>
-static void launch_conv_col_sum_n(const ConvIo &io, const ConvIo &iof, uint32_t tiles, const NttTables &T, const DevConv &cv,
-                                  hipStream_t s, hipStream_t s_int, bool pair_targets) {
-    // the integer-class instance (one target, q_0: a few hundred long-running workgroups) beside the fp64 one
+static void launch_conv_col_psum_n(const ConvIo &io, const ConvIo &iof, uint32_t tiles, const NttTables &T, const DevConv &cv,
+                                   hipStream_t s) {
     if (io.nsel) with_int_arith(T, [&](auto ar) {
-        k_conv_col_sum<LOG_H, N_IN, decltype(ar)::value, DevConv>
-            <<<dim3(io.items * tiles * io.nsel), NTT_THREADS, 0, s_int>>>(io, T, cv);
+        k_conv_col_psum<LOG_H, N_IN, decltype(ar)::value, DevConv>
+            <<<dim3(io.items * tiles * io.nsel), NTT_THREADS, 0, s>>>(io, T, cv);
     });
-    if (iof.nsel) {
-        if constexpr (N_IN <= 4) {
-            if (pair_targets) {  // two fp64 targets per workgroup: half the source traffic through L2
-                k_conv_col_sum2<LOG_H, N_IN, DevConv>
-                    <<<dim3(iof.items * tiles * ((iof.nsel + 1) / 2)), NTT_THREADS, 0, s>>>(iof, T, cv);
-                return;
-            }
-        }
-        {
-            k_conv_col_sum<LOG_H, N_IN, AR_FP, DevConv><<<dim3(iof.items * tiles * iof.nsel), NTT_THREADS, 0, s>>>(iof, T, cv);
-        }
-    }
+    if (iof.nsel)
+        k_conv_col_psum<LOG_H, N_IN, AR_FP, DevConv><<<dim3(iof.items * tiles * iof.nsel), NTT_THREADS, 0, s>>>(iof, T, cv);
 }
 template <int LOG_H>
-static void launch_conv_col_sum_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, hipStream_t s, hipStream_t s_int,
-                                  bool pair_targets) {
+static void launch_conv_col_psum_h(const ConvIo &io0, const NttTables &T, const DevConv &cv, hipStream_t s) {
     const uint32_t tiles = (1u << T.log_r2) / (256u >> LOG_H);
     ConvIo io = io0, iof = io0;
     io.target_mask = iof.target_mask = 0;
@@ -1016,22 +1002,38 @@ static void launch_conv_col_sum_h(const ConvIo &io0, const NttTables &T, const D
     io.nsel = (uint32_t)__builtin_popcountll(io.target_mask);
     iof.nsel = (uint32_t)__builtin_popcountll(iof.target_mask);
     switch (cv.n_in) {
-        case 1: launch_conv_col_sum_n<LOG_H, 1>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
-        case 2: launch_conv_col_sum_n<LOG_H, 2>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
-        case 3: launch_conv_col_sum_n<LOG_H, 3>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
-        case 4: launch_conv_col_sum_n<LOG_H, 4>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
-        case 5: launch_conv_col_sum_n<LOG_H, 5>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
-        case 6: launch_conv_col_sum_n<LOG_H, 6>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
-        case 7: launch_conv_col_sum_n<LOG_H, 7>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
-        case 8: launch_conv_col_sum_n<LOG_H, 8>(io, iof, tiles, T, cv, s, s_int, pair_targets); break;
+        case 1: launch_conv_col_psum_n<LOG_H, 1>(io, iof, tiles, T, cv, s); break;
+        case 2: launch_conv_col_psum_n<LOG_H, 2>(io, iof, tiles, T, cv, s); break;
+        case 3: launch_conv_col_psum_n<LOG_H, 3>(io, iof, tiles, T, cv, s); break;
+        case 4: launch_conv_col_psum_n<LOG_H, 4>(io, iof, tiles, T, cv, s); break;
+        case 5: launch_conv_col_psum_n<LOG_H, 5>(io, iof, tiles, T, cv, s); break;
+        case 6: launch_conv_col_psum_n<LOG_H, 6>(io, iof, tiles, T, cv, s); break;
+        case 7: launch_conv_col_psum_n<LOG_H, 7>(io, iof, tiles, T, cv, s); break;
+        case 8: launch_conv_col_psum_n<LOG_H, 8>(io, iof, tiles, T, cv, s); break;
         default: throw std::invalid_argument("base conversion fan-in unsupported");
     }
 }
-static void launch_conv_col_sum(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s, hipStream_t s_int,
-                                bool pair_targets) {
+static void launch_conv_col_psum(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s) {
     switch (fast_log_h(T.log_r1, 1u << T.log_r2)) {
-        case 4: launch_conv_col_sum_h<4>(io, T, cv, s, s_int, pair_targets); break;
-        case 3: launch_conv_col_sum_h<3>(io, T, cv, s, s_int, pair_targets); break;
+        case 4: launch_conv_col_psum_h<4>(io, T, cv, s); break;
+        case 3: launch_conv_col_psum_h<3>(io, T, cv, s); break;
+        default: throw std::logic_error("summed conversion needs 64- or 256-point columns");
+    }
+    MK_HIP(hipGetLastError());
+}
+// inverse column pass of the P limbs of every client of a group, summed over the clients as integers (k_icol_sum)
+static void launch_icol_sum(const u64 *pc, u64 *psum, const NttTables &T, const u64 *scale, const u64 *scale_sh, uint32_t K,
+                            uint32_t n_polys, uint32_t n_clients, size_t in_cstride, hipStream_t s) {
+    const uint32_t r2 = 1u << T.log_r2;
+    switch (fast_log_h(T.log_r1, r2)) {
+        case 4: with_int_arith(T, [&](auto ar) {
+            k_icol_sum<4, decltype(ar)::value>
+                <<<dim3(r2 / 16, n_polys * K), NTT_THREADS, 0, s>>>(pc, psum, T, scale, scale_sh, K, n_clients, in_cstride);
+        }); break;
+        case 3: with_int_arith(T, [&](auto ar) {
+            k_icol_sum<3, decltype(ar)::value>
+                <<<dim3(r2 / 32, n_polys * K), NTT_THREADS, 0, s>>>(pc, psum, T, scale, scale_sh, K, n_clients, in_cstride);
+        }); break;
         default: throw std::logic_error("summed conversion needs 64- or 256-point columns");
     }
     MK_HIP(hipGetLastError());
@@ -1661,7 +1663,11 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
     for (uint32_t i = 0; i < nl; ++i) (tabs_.h_fp_of[i] ? fp_mask : intq_mask) |= 1ull << i;
     for (uint32_t i = nl; i < ext; ++i) p_mask |= 1ull << i;
     const uint32_t n_intq = (uint32_t)__builtin_popcountll(intq_mask);
-    const uint32_t group = std::min(n_clients, knobs_.qsum_group);
+    // clients per pass: the group's P-limb coefficients are summed as 64-bit integers (k_icol_sum), so a group holds at
+    // most floor((2^64 - 1) / max p_k) clients (15 for 60-bit P limbs)
+    u64 max_p = 1;
+    for (uint32_t k = 0; k < K; ++k) max_p = std::max(max_p, ps_.moduli[ps_.L + k]);
+    const uint32_t group = std::min({n_clients, knobs_.qsum_group, (uint32_t)std::min<u64>(64, ~0ull / max_p)});
     const bool wide_rows = fast_row(tabs_.log_r2, 1u << tabs_.log_r1) == 9;  // N = 2^17: 512-point rows, three-round kernels
     // One stream: running the memory-bound sums of group g on a second stream beside the multiply-bound phases of group
     // g+1 was measured neutral to slightly negative (20.47 k against 20.59 k ct/s at groups of 4): both kinds of kernel
@@ -1671,13 +1677,15 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
     const size_t w_pc = (size_t)max_items * 2 * K * n;
     const size_t w_til = (size_t)max_items * 2 * n_intq * n;
     const size_t w_csum = (size_t)std::min(knobs_.chunk, n_ct) * 2 * nl * n;  // conversions summed over a group's clients
-    u64 *ws = workspace(w_coef + w_dig + w_pc + w_til + w_csum);
+    const size_t w_psum = (size_t)std::min(knobs_.chunk, n_ct) * 2 * K * n;   // P-limb coefficients summed over a group's clients
+    u64 *ws = workspace(w_coef + w_dig + w_pc + w_til + w_csum + w_psum);
     hipStream_t main = stream_;
     for (uint32_t b0 = 0; b0 < n_ct; b0 += knobs_.chunk) {
         const uint32_t cnt = std::min(knobs_.chunk, n_ct - b0);
         for (uint32_t g0 = 0; g0 < n_clients; g0 += group) {
             const uint32_t gc = std::min(group, n_clients - g0), items = gc * cnt;
             u64 *coef = ws, *dig = coef + w_coef, *pc = dig + w_dig, *til = pc + w_pc, *convsum = til + w_til;
+            u64 *psum = convsum + w_csum;
             const u64 *ct0 = cts + ((size_t)g0 * n_ct + b0) * ct_words;  // client g0, index b0
             const u64 *c1 = ct0 + (size_t)nl * n, *evk0 = evks + (size_t)g0 * evk_words;
             const size_t ct_cstride = (size_t)n_ct * ct_words;
@@ -1700,27 +1708,12 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
                 if (wide_rows) launch_row3_inner_int_k<3, true>(ap, tabs_, nparts, ps_.L, pc, K, main);
                 else launch_row3_inner_int_k<2, true>(ap, tabs_, nparts, ps_.L, pc, K, main);
             }
-            {   // ApproxModDown: inverse column pass of every item's P limbs (in place on pc), then the conversion
-                // P -> Q_l: fp64-class targets summed over the group's clients before ONE forward column pass
-                // (k_conv_col_sum), integer-class targets (q_0) per client as before
+            {   // ApproxModDown: inverse column pass of every item's P limbs, summed over the group's clients as integers
+                // (k_icol_sum), then ONE conversion P -> Q_l and forward column pass per (index, component, target limb)
                 const u64 *fold = folded_scale(nl);
-                NttIo pin{pc, pc, (size_t)K * n, (size_t)K * n, 0, 0, nl, K, nl};
-                launch_col<true>(pin, tabs_, 2 * items, fold, fold + D, lanes(), 1);
-                MK_HIP(hipGetLastError());
-                const DevConv &cv = moddown_conv(nl);
-                ConvIo cs{pc, convsum, (size_t)K * n, (size_t)nl * n, 2 * cnt, 0, 0};
-                cs.n_clients = gc;
-                cs.in_cstride = (size_t)cnt * 2 * K * n;
-                const bool fork = n_intq != 0 && side_stream_ != nullptr && !knobs_.one_lane;
-                if (fork) {
-                    MK_HIP(hipEventRecord(ev_fork_, main));
-                    MK_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
-                }
-                launch_conv_col_sum(cs, tabs_, cv, main, fork ? side_stream_ : main, knobs_.conv_pairs);
-                if (fork) {
-                    MK_HIP(hipEventRecord(ev_join_, side_stream_));
-                    MK_HIP(hipStreamWaitEvent(main, ev_join_, 0));
-                }
+                launch_icol_sum(pc, psum, tabs_, fold, fold + D, K, 2 * cnt, gc, (size_t)cnt * 2 * K * n, main);
+                ConvIo cs{psum, convsum, (size_t)K * n, (size_t)nl * n, 2 * cnt, 0, 0};
+                launch_conv_col_psum(cs, tabs_, moddown_conv(nl), main);
             }
             if (n_intq) {  // integer-class Q limbs: accumulators through a compact til
                 InnerArgs aq = ia;

@@ -59,7 +59,6 @@ struct Knobs {
     int qsum_geom = 3;           // MKCKKS_QSUM_GEOM: 3 = three-round k_qsum3_fp (3 waves per SIMD), 2 = two-round k_qsum_fp
     bool generic_ntt = false;    // MKCKKS_GENERIC_NTT=1: LDS-stage kernels for both passes
     bool no_pm = false;          // MKCKKS_NO_PM=1: Shoup butterflies on the integer limbs instead of the pseudo-Mersenne ones
-    bool conv_pairs = true;      // MKCKKS_CONV_PAIRS=0: one target limb per workgroup in the summed ModDown conversion (k_conv_col_sum2 off)
     bool no_fp64 = false;        // MKCKKS_NO_FP64=1: integer arithmetic on every limb
     bool fuse_inner = true;      // MKCKKS_FUSE_INNER=0: separate row pass + inner product (all limbs)
     bool fuse_inner_int = true;  // MKCKKS_FUSE_INNER_INT=0: ... for the integer limbs only

@@ -439,9 +439,6 @@ struct ConvIo {
     uint32_t items;
     unsigned long long target_mask;  // targets (indices into cv.dst_*) of this instance's arithmetic class
     uint32_t nsel;                   // popcount(target_mask)
-    // k_conv_col_sum: item i of client c is read at in + c * in_cstride + i * in_stride
-    uint32_t n_clients = 1;
-    size_t in_cstride = 0;
 };
 // canonical integer below 2^52 held in a double -> its 30-bit halves (what split30 gives for the u64)
 MK_D void split30_d(u64 dbl_bits, uint32_t &lo, uint32_t &hi) {
@@ -554,22 +551,80 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTable
     col_forward_finish<LOG_H, AR>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
 }
 
-// ApproxModDown's conversion P -> Q_l for an fp64-class target, SUMMED OVER CLIENTS before the forward transform:
-//   conv_sum[t] = sum_c ApproxSwitchCRTBasis_c[t]  (coefficient format, mod q_t),  then ONE forward column pass.
-// The reference transforms every client's conversion separately (ApproxModDown inside each ReEncrypt) and adds the
-// results afterwards (EvalAdd); the transform is linear over Z_{q_t}, so  sum_c NTT(conv_c) = NTT(sum_c conv_c)  residue
-// for residue -- each client's conversion is still computed on its own (the approximate conversion is NOT additive in
-// its input; only what follows it is linear).  n - 1 of the n forward transforms per (index, component, limb) disappear.
-// Sources: the K P-limbs of every client as packed 30-bit halves (integer class).
+// ---- ApproxModDown's conversion P -> Q_l for a whole group of clients at once ------------------------------------------
+// The reference converts every client's key-switch result on its own (ApproxModDown inside each ReEncrypt) and adds the
+// re-encryptions afterwards (EvalAdd).  With x_{c,k} the canonical residue mod p_k of client c's coefficient (the inverse
+// transform of its P limb k, scaled by N^-1 [(P/p_k)^-1]_{p_k}), the conversion into the target q_t is
+//     conv_c[t] = ( sum_k x_{c,k} [P/p_k]_t ) mod q_t ,
+// and what the aggregate needs is  sum_c conv_c[t] mod q_t = ( sum_k X_k [P/p_k]_t ) mod q_t  with  X_k = sum_c x_{c,k}
+// taken as an INTEGER (no reduction mod p_k: the approximate conversion is not additive in residues mod p_k, it is
+// additive in their integer representatives).  n <= 15 residues below 2^60 fit a 64-bit word, so the group's clients
+// are summed where their coefficients are produced (k_icol_sum, inside the inverse column pass) and converted ONCE
+// (k_conv_col_psum): n - 1 of the n conversions per (index, component, target limb) and n - 1 of the n writes of the
+// P-limb coefficients disappear, and the result is the same residue mod q_t, bit for bit.
+//
+// k_icol_sum: inverse COLUMN pass of the P limbs (second pass of ApproxModDown's SetFormat(COEFFICIENT)) of every client
+// of the group, scaled to canonical residues and summed over the clients as 64-bit integers.
+//   pc:   [client][poly][K][N]  outputs of the inverse row pass (lazy), clients in_cstride words apart
+//   psum: [poly][K][N]          X_k = sum over clients, < n_clients * p_k < 2^64
+// grid (column tile, poly * K + k); the host caps the group so that the sum cannot wrap.
+template <int LOG_H, int AR>
+__global__ __launch_bounds__(NTT_THREADS, 3) void k_icol_sum(const u64 *pc, u64 *psum, NttTables T, const u64 *scale,
+                                                             const u64 *scale_sh, uint32_t K, uint32_t n_clients,
+                                                             size_t in_cstride) {
+    using TL = ColTile<LOG_H>;
+    constexpr int H = TL::H, S = TL::S;
+    static_assert(AR != AR_FP, "P limbs are integer-class");
+    __shared__ u64 lds[TL::WORDS];
+    const uint32_t poly = blockIdx.y / K, k = blockIdx.y % K;
+    const uint32_t id = T.L + k;
+    const LimbConst lc = T.limb[id];
+    const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2;
+    const int c = threadIdx.x % S, j = threadIdx.x / S;
+    const size_t off = ((size_t)poly * K + k) * n + blockIdx.x * S + c;
+    const u64 *itw = T.itw + (size_t)id * n, *itw_sh = T.itw_sh + (size_t)id * n;
+    const u64 sc = scale[id], sc_sh = scale_sh[id];
+    u64 acc[H];
+#pragma unroll
+    for (int kk = 0; kk < H; ++kk) acc[kk] = 0;
+#pragma unroll 1
+    for (uint32_t cl = 0; cl < n_clients; ++cl) {
+        const u64 *src = pc + (size_t)cl * in_cstride + off;
+        u64 x[H], w[H - 1], wp[H - 1];
+#pragma unroll
+        for (int kk = 0; kk < H; ++kk) x[kk] = ld_pass(src + (size_t)(H * j + kk) * r2);
+        load_round_twiddles<LOG_H>(itw, itw_sh, (uint32_t)(H + j), w, wp);
+        radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
+        if (cl) __syncthreads();  // the previous client's exchange is read out
+#pragma unroll
+        for (int kk = 0; kk < H; ++kk) lds[TL::at(j, kk, c)] = x[kk];
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < H; ++kk) x[kk] = lds[TL::at(kk, j, c)];
+        load_round_twiddles<LOG_H>(itw, itw_sh, 1u, w, wp);
+        radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
+#pragma unroll
+        for (int kk = 0; kk < H; ++kk) acc[kk] += shoup_mul(x[kk], sc, sc_sh, lc.q);  // canonical, as the per-client pass stores it
+    }
+    u64 *dst = psum + off;
+#pragma unroll
+    for (int kk = 0; kk < H; ++kk) st_pass(dst + (size_t)(j + H * kk) * r2, acc[kk]);
+}
+
+// k_conv_col_psum: the ONE conversion of a group, sum_k X_k [P/p_k]_t mod q_t, fused into the forward column pass of the
+// target limb (k_conv_col's structure; grid over (poly, column tile, target), the targets of a source tile neighbours in
+// one XCD's queue).  Sources: the K integer sums X_k (any 64-bit word); each is first reduced mod q_t -- an fp64-class
+// target splits it into 32-bit halves, (X_hi [2^32]_t + X_lo) [P/p_k]_t as two exact FMA products; an integer-class
+// target (q_0) takes one Barrett step and the 30-bit column accumulation of k_conv_col.
 template <int LOG_H, int N_IN, int AR, typename CONV>
-__global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_sum(ConvIo io, NttTables T, CONV cv) {
+__global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_psum(ConvIo io, NttTables T, CONV cv) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
     __shared__ u64 lds[TL::WORDS];
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
     const uint32_t groups = io.items * tiles;
     uint32_t grp, jt;
-    if (groups % 8 == 0) {  // the targets of one source tile: neighbours in one XCD's queue (see k_conv_col)
+    if (groups % 8 == 0) {
         const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
         grp = (qidx / io.nsel) * 8 + xcd;
         jt = qidx % io.nsel;
@@ -583,126 +638,61 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_sum(ConvIo io, NttT
     const LimbConst lc = T.limb[id];
     if ((lc.fp != 0) != (AR == AR_FP)) return;  // never: the host selects the targets of this instance's class
     const int c = threadIdx.x % S, j = threadIdx.x / S;
-    const u64 *src0 = io.in + (size_t)item * io.in_stride + tile * S + c;
+    const u64 *src = io.in + (size_t)item * io.in_stride + tile * S + c;
     u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jt] * n + tile * S + c;
-    uint32_t h0[N_IN], h1[N_IN];
+    u64 x[H];
+    if (AR == AR_FP) {
+        double hd[N_IN], hq[N_IN];
 #pragma unroll
-    for (int i = 0; i < N_IN; ++i) split30(cv.hat[i * cv.n_out + jt], h0[i], h1[i]);
-    // running sums: exact doubles below 0.51 q + 4 q (fp64 class) or lazy integers below 4 q (integer class, q < 2^60)
-    double sum[H];
-    u64 isum[H];
+        for (int i = 0; i < N_IN; ++i) {
+            hd[i] = cv.hat_d[i * cv.n_out + jt];
+            hq[i] = cv.hatq_d[i * cv.n_out + jt];
+        }
+        // 2^32 mod q_t; its quotient by q_t only steers fp_mulmod's choice of representative (the product is exact
+        // for any integer quotient near the true one), so the double rounding of c32 * qinv is harmless
+        const double c32 = (double)reduce_word(1ull << 32, lc), c32q = c32 * lc.qinv;
 #pragma unroll
-    for (int k = 0; k < H; ++k) {
-        sum[k] = 0.0;
-        isum[k] = 0;
-    }
-    const u64 q4 = lc.q2 + lc.q2;
-#pragma unroll 1
-    for (uint32_t cl = 0; cl < io.n_clients; ++cl) {
-        const u64 *src = src0 + (size_t)cl * io.in_cstride;
-        // the H * N_IN load offsets do not depend on the client: left alone, the compiler computes all of them once in
-        // front of the loop and keeps 2 registers each alive across it (115 spilled registers at 4 waves per SIMD).
-        // Offsets derived from values that are opaque per iteration are recomputed where they are used instead.
-        uint32_t r2v = r2, nv = n;
-        asm volatile("" : "+s"(r2v), "+s"(nv));
+        for (int kk = 0; kk < H; ++kk) {
+            double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < H; ++k) {
-            u64 v;
+            for (int i = 0; i < N_IN; ++i) {
+                const u64 p = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * kk) * r2];
+                // X = hi 2^32 + lo:  r = hi [2^32]_t + lo,  |r| <= 0.51 q + 2^32 < 2^52
+                const double r = fp_mulmod((double)(uint32_t)(p >> 32), c32, c32q, lc.qd) + (double)(uint32_t)p;
+                acc += fp_mulmod(r, hd[i], hq[i], lc.qd);  // |.| <= 0.76 q each: < 2^53 for 8 sources
+            }
+            x[kk] = dbits(fp_reduce(acc, lc.qd, lc.qinv));
+        }
+    } else {
+        uint32_t h0[N_IN], h1[N_IN];
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i) split30(cv.hat[i * cv.n_out + jt], h0[i], h1[i]);
+#pragma unroll
+        for (int kk = 0; kk < H; ++kk) {
             if (N_IN <= 4) {
                 Cols acc{0, 0, 0};
 #pragma unroll
                 for (int i = 0; i < N_IN; ++i) {
-                    const u64 p = src[cv.src_slot[i] * nv + (uint32_t)(j + H * k) * r2v];
-                    mac_cols(acc, (uint32_t)p, (uint32_t)(p >> 32), h0[i], h1[i]);
+                    const u64 r = reduce_word(src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * kk) * r2], lc);
+                    uint32_t a0, a1;
+                    split30(r, a0, a1);
+                    mac_cols(acc, a0, a1, h0[i], h1[i]);
                 }
-                v = reduce_cols_lazy(acc, lc);  // < 4q < 2^53
+                x[kk] = AR == AR_PM ? pm_reduce_cols(acc, pm_consts(lc)) : reduce_cols_lazy(acc, lc);  // < 4q
             } else {
                 Cols4 acc{0, 0, 0, 0};
 #pragma unroll
                 for (int i = 0; i < N_IN; ++i) {
-                    const u64 p = src[cv.src_slot[i] * nv + (uint32_t)(j + H * k) * r2v];
-                    mac_cols4(acc, (uint32_t)p, (uint32_t)(p >> 32), h0[i], h1[i]);
+                    const u64 r = reduce_word(src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * kk) * r2], lc);
+                    uint32_t a0, a1;
+                    split30(r, a0, a1);
+                    mac_cols4(acc, a0, a1, h0[i], h1[i]);
                 }
-                v = reduce_cols4(acc, lc);
+                x[kk] = reduce_cols4(acc, lc);
             }
-            if (AR == AR_FP) sum[k] = fp_reduce(sum[k] + (double)v, lc.qd, lc.qinv);
-            else isum[k] = csub(isum[k] + (N_IN <= 4 ? v : v), q4);  // < 4q + 4q < 2^63, back below 4q
         }
     }
-    u64 x[H];
-#pragma unroll
-    for (int k = 0; k < H; ++k) x[k] = (AR == AR_FP) ? dbits(sum[k]) : isum[k];  // integer: < 4q, the first stage accepts < 8q
     col_forward_finish<LOG_H, AR>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
-}
-
-// k_conv_col_sum for TWO fp64-class targets per workgroup.  The source tiles are the same for every target limb: with one
-// target per workgroup the 12 targets pull the 512 MiB of P limbs of a step through L2 twelve times (6 GiB at the
-// 8-byte-access rate -- about the duration of that kernel); forming two conversions from one load halves it.  Two sets of
-// running sums: 3 waves per SIMD instead of 4; the two column passes run one after the other.  The last group of an odd
-// target count carries one live target.
-template <int LOG_H, int N_IN, typename CONV>
-__global__ __launch_bounds__(NTT_THREADS, 3) void k_conv_col_sum2(ConvIo io, NttTables T, CONV cv) {
-    using TL = ColTile<LOG_H>;
-    constexpr int H = TL::H, S = TL::S, NT = 2;
-    static_assert(N_IN <= 4, "target pairs: at most 4 sources (plain three-column accumulation)");
-    __shared__ u64 lds[TL::WORDS];
-    const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
-    const uint32_t groups = io.items * tiles, ntg = (io.nsel + NT - 1) / NT;
-    uint32_t grp, jg;
-    if (groups % 8 == 0) {  // the target groups of one source tile: neighbours in one XCD's queue (see k_conv_col)
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / ntg) * 8 + xcd;
-        jg = qidx % ntg;
-    } else {
-        grp = blockIdx.x / ntg;
-        jg = blockIdx.x % ntg;
-    }
-    const uint32_t item = grp / tiles, tile = grp % tiles;
-    const bool two = jg * NT + 1 < io.nsel;  // workgroup-uniform
-    const uint32_t jta = nth_set_bit(io.target_mask, jg * NT), jtb = two ? nth_set_bit(io.target_mask, jg * NT + 1) : jta;
-    const uint32_t ida = cv.dst_id[jta], idb = cv.dst_id[jtb];
-    const LimbConst la = T.limb[ida], lb = T.limb[idb];
-    if (!la.fp || !lb.fp) return;  // never: the host selects fp64-class targets
-    const int c = threadIdx.x % S, j = threadIdx.x / S;
-    const u64 *src0 = io.in + (size_t)item * io.in_stride + tile * S + c;
-    uint32_t a0[N_IN], a1[N_IN], b0[N_IN], b1[N_IN];
-#pragma unroll
-    for (int i = 0; i < N_IN; ++i) {
-        split30(cv.hat[i * cv.n_out + jta], a0[i], a1[i]);
-        split30(cv.hat[i * cv.n_out + jtb], b0[i], b1[i]);
-    }
-    double sa[H], sb[H];  // exact doubles below 0.51 q + 4 q
-#pragma unroll
-    for (int k = 0; k < H; ++k) sa[k] = sb[k] = 0.0;
-#pragma unroll 1
-    for (uint32_t cl = 0; cl < io.n_clients; ++cl) {
-        const u64 *src = src0 + (size_t)cl * io.in_cstride;
-        uint32_t r2v = r2, nv = n;  // opaque per iteration: see k_conv_col_sum
-        asm volatile("" : "+s"(r2v), "+s"(nv));
-#pragma unroll
-        for (int k = 0; k < H; ++k) {
-            Cols ca{0, 0, 0}, cb{0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < N_IN; ++i) {
-                const u64 p = src[cv.src_slot[i] * nv + (uint32_t)(j + H * k) * r2v];
-                mac_cols(ca, (uint32_t)p, (uint32_t)(p >> 32), a0[i], a1[i]);
-                mac_cols(cb, (uint32_t)p, (uint32_t)(p >> 32), b0[i], b1[i]);
-            }
-            sa[k] = fp_reduce(sa[k] + (double)reduce_cols_lazy(ca, la), la.qd, la.qinv);
-            sb[k] = fp_reduce(sb[k] + (double)reduce_cols_lazy(cb, lb), lb.qd, lb.qinv);
-        }
-    }
-    u64 x[H];
-#pragma unroll
-    for (int k = 0; k < H; ++k) x[k] = dbits(sa[k]);
-    u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jta] * n + tile * S + c;
-    col_forward_finish<LOG_H, AR_FP>(x, lds, T.tw + (size_t)ida * n, T.tw_sh + (size_t)ida * n, la, j, c, dst, r2);
-    if (!two) return;
-    __syncthreads();  // the first target's exchange is read out
-#pragma unroll
-    for (int k = 0; k < H; ++k) x[k] = dbits(sb[k]);
-    dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jtb] * n + tile * S + c;
-    col_forward_finish<LOG_H, AR_FP>(x, lds, T.tw + (size_t)idb * n, T.tw_sh + (size_t)idb * n, lb, j, c, dst, r2);
 }
 
 // DropLastElementAndScale, first half fused: NativeVectorT::SwitchModulus of the dropped limb (COEFFICIENT format,

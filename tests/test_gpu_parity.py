@@ -480,7 +480,6 @@ def test_reencrypt_sum(ctxs, name, nl, C, B):
                                  {"MKCKKS_SUM_ONE_LANE": "1"},    # clients strictly one after the other
                                  {"MKCKKS_NO_PM": "1"},           # Shoup butterflies on q_0 and the P limbs
                                  {"MKCKKS_NO_PM": "1", "MKCKKS_QSUM": "0"},
-                                 {"MKCKKS_CONV_PAIRS": "0"},      # one target limb per workgroup in the summed ModDown conversion
                                  {"MKCKKS_QSUM_GEOM": "4"},       # three-round k_qsum3_fp at 2 waves per SIMD
                                  {"MKCKKS_NO_FP64": "1"},         # integer (Shoup) arithmetic on every limb
                                  {"MKCKKS_NO_FP64": "1", "MKCKKS_QSUM": "0"},
@@ -801,6 +800,54 @@ def test_full_size_batch_properties(ctxs):
     assert torch.equal(raw, ref)
     torch.cuda.synchronize()
     g.set_stream(None)
+
+
+def test_config4_sixty_four_clients_on_one_rank(ctxs):
+    """BASELINE configs[3]'s workload (64 clients, N=2^16, L=12, dnum=3) as far as ONE GPU goes: the server loop of
+    server/src/aggregateEncryptedWeights.cpp:68-115 generalised to 64 clients -- changeCipherDomain x 64
+    (orchestration/server_fns.sh:62-80), the EvalAdd chain, EvalMult(1/64).  reencrypt_sum runs 8 groups of 8 clients
+    with the running sum carried through `out`; index 0 is checked against the oracle's ReEncrypt x 64 + EvalAdd chain +
+    rescale * const, index 1 against re-encrypt-each-then-eval_sum on the device (different kernels, same bits).  The
+    sharded leg (8 ranks x 8 clients, RCCL reduce-scatter) is covered on CPU by tests/test_sharding_gloo.py at world
+    size 8; only its 8-GPU hardware run is left to the driver."""
+    import torch
+    g, o = ctxs("c3")
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(64)
+    C, B, L, N, D = 64, 2, g.L, g.N, g.D
+
+    def uniform(lead, ids):
+        t = torch.empty(*lead, len(ids), N, dtype=torch.int64, device=dev)
+        for j, l in enumerate(ids):
+            t[..., j, :] = torch.randint(0, int(g.moduli[l]), (*lead, N), generator=gen, device=dev, dtype=torch.int64)
+        return t
+
+    cts = uniform((C, B), list(range(L)) * 2).view(C, B, 2, L, N)
+    evks = uniform((C,), list(range(D)) * (2 * g.beta)).view(C, g.beta, 2, D, N)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    agg = torch.empty(B, 2, L, N, dtype=torch.int64, device=dev)
+    g.reencrypt_sum(cts, evks, agg, C, B, L)
+    avg = torch.empty(B, 2, L - 1, N, dtype=torch.int64, device=dev)
+    g.rescale_mult_const(agg, avg, B, L, 1.0 / C)
+    # index 1: every client re-encrypted on its own, n-ary EvalAdd
+    each = torch.empty(C, 1, 2, L, N, dtype=torch.int64, device=dev)
+    for c in range(C):
+        g.reencrypt(cts[c, 1:2], evks[c], each[c], 1, L)
+    ref1 = torch.empty(1, 2, L, N, dtype=torch.int64, device=dev)
+    g.eval_sum(each, ref1, C, 1, L)
+    assert torch.equal(agg[1], ref1[0])
+    torch.cuda.synchronize()
+    g.set_stream(None)
+    # index 0: the oracle's chain
+    h_ct = cts[:, 0].cpu().numpy().view(np.uint64)
+    acc = None
+    for c in range(C):
+        r = o.reencrypt(h_ct[c], evks[c].cpu().numpy().view(np.uint64))
+        acc = r if acc is None else o.eval_add(acc, r)
+    assert np.array_equal(agg[0].cpu().numpy().view(np.uint64), acc)
+    exp = o.mult_factors(o.rescale(acc), o.const_factors(L - 1, 1, 1.0 / C))
+    assert np.array_equal(avg[0].cpu().numpy().view(np.uint64), exp)
 
 
 def test_rccl_reduce_scatter_through_the_cabi(ctxs):

@@ -16,29 +16,32 @@ MODULI = [1152921504606748673, 1125899908022273, 1125899904679937, 557057]  # 60
 N, B = 256, 4
 
 
-def _partial(rank):
+def _partial(rank, n_ct=B, extreme=False):
     rng = np.random.default_rng(100 + rank)
-    x = np.empty((B, 2, len(MODULI), N), dtype=np.uint64)
+    x = np.empty((n_ct, 2, len(MODULI), N), dtype=np.uint64)
     for i, q in enumerate(MODULI):
-        x[:, :, i, :] = rng.integers(0, q, size=(B, 2, N), dtype=np.uint64)
+        x[:, :, i, :] = rng.integers(0, q, size=(n_ct, 2, N), dtype=np.uint64)
         x[:, :, i, 0] = q - 1  # extreme residues
+        if extreme:  # every rank's partial sum at the top of its range: the 8-term integer sum is as large as it gets
+            x[:, :, i, : N // 2] = q - 1
     return x
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, n_ct=B, extreme=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    part = torch.from_numpy(_partial(rank).view(np.int64))
+    part = torch.from_numpy(_partial(rank, n_ct, extreme).view(np.int64))
     shard = reduce_partial_sums(part)
-    lo, hi = shard_range(B, rank, world)
-    total = sum(_partial(r).astype(object) for r in range(world))  # exact integers
+    lo, hi = shard_range(n_ct, rank, world)
+    assert (lo, hi) == (rank * (n_ct // world), (rank + 1) * (n_ct // world))  # rank r owns the r-th block of the aggregate
+    total = sum(_partial(r, n_ct, extreme).astype(object) for r in range(world))  # exact integers
     got = shard.numpy().view(np.uint64)
     ok = True
     for i, q in enumerate(MODULI):
         exp = np.array(total[lo:hi, :, i, :] % q, dtype=np.uint64)
         ok &= bool(np.array_equal(got[:, :, i, :] % np.uint64(q), exp))
-    ok &= shard.shape == (B // world, 2, len(MODULI), N)
+    ok &= shard.shape == (n_ct // world, 2, len(MODULI), N)
     ret[rank] = ok
     dist.barrier()
     dist.destroy_process_group()
@@ -58,6 +61,18 @@ def test_two_rank_integer_reduce_scatter_matches_modular_sum():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def test_eight_rank_extreme_partial_sums_and_shard_ownership():
+    # BASELINE configs[3] (64 clients over 8 GPUs: 8 clients per rank, one partial sum per rank): the collective's
+    # arithmetic at world size 8 with every rank's partial sum at q - 1 on half of the coefficients -- the largest
+    # 8-term integer sum there is -- and rank r left with ciphertexts [r, r + 1) of the 8 aggregates.  (The hardware
+    # leg, RCCL over xGMI on 8 MI355X, is the driver's to run.)
+    world = 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret, 8, True), nprocs=world, join=True)
+    assert len(ret) == world and all(ret[r] for r in range(world)), dict(ret)
 
 
 def test_eight_canonical_terms_never_wrap():

@@ -201,6 +201,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1536,
                     help="ciphertexts in the CPU-baseline sample (about 17 s on 16 cores; the 1-thread leg takes 1/48 of it)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="repeat the timed block of --steps steps until this much of it has run; report the median block")
+    ap.add_argument("--max-blocks", type=int, default=64)
     ap.add_argument("--verify", action="store_true",
                     help="N>1 only, after the timed region: check the integer reduce-scatter + reduce_mod + rescale "
                          "result against the modular sum of the gathered per-rank aggregates")
@@ -393,19 +396,35 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    fence()
-    dt = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels run on
-    if world > 1:
-        t = torch.tensor([dt, gpu_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, gpu_ms = float(t[0]), float(t[1])
+
+    def timed_block():
+        """EXACTLY --steps steps between two fences (device synchronize + barrier on both sides); MAX over ranks of the
+        wall time and of the HIP-event time on the stream the kernels run on."""
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps):
+            step()
+        ev1.record()
+        fence()
+        dt_b = time.perf_counter() - t0
+        ms_b = ev0.elapsed_time(ev1)
+        if world > 1:
+            t = torch.tensor([dt_b, ms_b], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_b, ms_b = float(t[0]), float(t[1])
+        return dt_b, ms_b
+
+    # the timed block is repeated until about --min-seconds of it have run (a 20-step block is 0.1 s): the reported
+    # figures are those of the MEDIAN block, with the fastest and the slowest beside them.  Every rank derives the same
+    # repeat count from the first block's max-over-ranks time.
+    blocks = [timed_block()]
+    n_blocks = max(1, min(args.max_blocks, int(np.ceil(args.min_seconds / max(blocks[0][0], 1e-6)))))
+    while len(blocks) < n_blocks:
+        blocks.append(timed_block())
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
+    dt, gpu_ms = blocks[order[(len(order) - 1) // 2]]  # lower median: an actual block, never an interpolation
+    dt_min, dt_max = blocks[order[0]][0], blocks[order[-1]][0]
 
     if world > 1:
         gpu_ms = dt * 1e3  # the exchange runs on a second stream: the main-stream events miss it, wall time does not
@@ -443,7 +462,10 @@ def main():
     result = {
         "metric": f"ciphertexts/sec aggregated+PRE at N=2^{args.log_n}, L={L} RNS limbs",
         "value": value, "unit": "ciphertexts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt * 1e3 / args.steps, "ms_per_step_min": dt_min * 1e3 / args.steps,
+        "ms_per_step_max": dt_max * 1e3 / args.steps, "timed_blocks": len(blocks),
+        "timing": f"median of {len(blocks)} timed blocks of {args.steps} steps each (fence on both sides of every block)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"C3+C4: {C} clients x {B} ct per GPU, N=2^{args.log_n}, L={L}, K={K}, dnum={args.dnum}: "
                                + ("reencrypt_sum_batch (hybrid key-switch PRE of every client; row passes, inner product, "

@@ -484,6 +484,10 @@ Knobs Knobs::from_env() {
         const int v = std::atoi(e);
         if (v == 2 || v == 3 || v == 4) k.qsum_geom = v;
     }
+    if (const char *e = std::getenv("MKCKKS_STAGGER")) {
+        const int v = std::atoi(e);
+        if (v >= 0 && v <= 1000) k.stagger = (uint32_t)v;
+    }
     k.generic_ntt = env_flag("MKCKKS_GENERIC_NTT", k.generic_ntt);
     k.no_pm = env_flag("MKCKKS_NO_PM", k.no_pm);
     k.no_fp64 = env_flag("MKCKKS_NO_FP64", k.no_fp64);
@@ -536,6 +540,7 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device), knobs
         ps_.limb[i].pm_c = pm ? (uint32_t)(((u64)1 << ps_.limb[i].k) - ps_.moduli[i]) : 0u;
     }
     tabs_.h_fp_of = fp_of_.data();
+    tabs_.stagger = knobs_.stagger;
     MK_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));  // second client lane of reencrypt_sum
     MK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     MK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));

@@ -56,6 +56,8 @@ struct Knobs {
     uint32_t chunk = 16;         // MKCKKS_CHUNK: ciphertexts per workspace chunk
     uint32_t qsum_group = 8;     // MKCKKS_QSUM_GROUP: clients per pass of the merged n-client flow (one forward transform of
                                  // the summed ModDown conversions per group: 8 is +2.7 % against 4, 2 is -6.6 %)
+    uint32_t stagger = 0;        // MKCKKS_STAGGER: start-phase stagger of each pass's first generation of workgroups, percent of
+                                 // the built-in steps (ntt_radix.hpp: stagger_start); 0 = all workgroups start together
     int qsum_geom = 3;           // MKCKKS_QSUM_GEOM: 3 = three-round k_qsum3_fp (3 waves per SIMD), 2 = two-round k_qsum_fp
     bool generic_ntt = false;    // MKCKKS_GENERIC_NTT=1: LDS-stage kernels for both passes
     bool no_pm = false;          // MKCKKS_NO_PM=1: Shoup butterflies on the integer limbs instead of the pseudo-Mersenne ones

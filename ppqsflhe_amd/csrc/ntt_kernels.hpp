@@ -42,6 +42,7 @@ struct NttTables {
     uint32_t has_fp;  // some limbs run on the fp64 kernel instances (host launches both instances then)
     const unsigned char *h_fp_of;  // HOST pointer (never read on the device): per limb id, 1 = fp64 instance
     uint32_t int_pm;  // HOST decision: the integer limbs run on the AR_PM instances (all of them qualify), else AR_INT
+    uint32_t stagger;  // start-phase stagger of a kernel's first generation of workgroups, percent of the built-in steps (0 = off)
 };
 // arithmetic of a radix-kernel instance (template parameter AR; AR_INT / AR_FP keep the values of the old bool)
 constexpr int AR_INT = 0, AR_FP = 1, AR_PM = 2;

@@ -77,6 +77,21 @@ MK_D void st_stream2(ulong2 *p, ulong2 v) {
     }
 }
 
+// Start-phase stagger.  Every workgroup of a pass does the same amount of work, so the W workgroups that start together
+// on a CU stay in step for the whole launch: they wait for their loads at the same time (the SIMDs idle) and compete for
+// the VALU at the same time.  Delaying the FIRST generation's workgroups by 0 .. W-1 W-ths of a workgroup's lifetime puts
+// the residents of a CU into different phases, and every later workgroup inherits the phase of the one whose slot it
+// takes.  Workgroup b of the first generation lands on CU (b / 8) % 32 of XCD b % 8 (tools/probe_dispatch.hip), so
+// (b >> 8) % W enumerates the residents of a CU.  STEP: one W-th of the lifetime in s_sleep(16) units (1024 cycles).
+template <int W, int STEP>
+MK_D void stagger_start(uint32_t pct) {
+    if (!pct) return;
+    const uint32_t b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (b >= 256u * W) return;
+    const uint32_t n = ((b >> 8) % W) * (uint32_t)STEP * pct / 100u;
+    for (uint32_t i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+}
+
 // twiddles of one round: w[(1<<s) - 1 + g] = table[(base_eff << s) + g]
 template <int LOG_H>
 MK_D void load_round_twiddles(const u64 *__restrict__ tw, const u64 *__restrict__ tw_sh, uint32_t base_eff,
@@ -374,6 +389,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
     constexpr int H = TL::H, S = TL::S;
     __shared__ u64 lds[TL::WORDS];
     const uint32_t poly = blockIdx.y / io.nsel, sl = nth_set_bit(io.slot_mask, blockIdx.y % io.nsel);
+    stagger_start<4, 8>(T.stagger);
     if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;  // block-uniform
     const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
     const LimbConst lc = T.limb[id];
@@ -458,6 +474,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTable
     constexpr int H = TL::H, S = TL::S;
     static_assert(SRCMODE == 0 || N_IN <= 4, "double sources: at most 4 per digit");
     __shared__ u64 lds[TL::WORDS];
+    stagger_start<4, (AR == AR_FP ? 10 : 14)>(T.stagger);
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
     const uint32_t groups = io.items * tiles;  // source tiles
     uint32_t grp, jt;
@@ -576,6 +593,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_icol_sum(const u64 *pc, u64 
     constexpr int H = TL::H, S = TL::S;
     static_assert(AR != AR_FP, "P limbs are integer-class");
     __shared__ u64 lds[TL::WORDS];
+    stagger_start<3, 40>(T.stagger);
     const uint32_t poly = blockIdx.y / K, k = blockIdx.y % K;
     const uint32_t id = T.L + k;
     const LimbConst lc = T.limb[id];
@@ -621,6 +639,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_psum(ConvIo io, Ntt
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
     __shared__ u64 lds[TL::WORDS];
+    stagger_start<4, 12>(T.stagger);
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
     const uint32_t groups = io.items * tiles;
     uint32_t grp, jt;
@@ -705,6 +724,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_switch_col(const u64 *last, u64
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
     __shared__ u64 lds[TL::WORDS];
+    stagger_start<4, 8>(T.stagger);
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2;
     const uint32_t sl = nth_set_bit(target_mask, blockIdx.y), item = blockIdx.z;  // remaining Q limb: slot == limb id
     const LimbConst lc = T.limb[sl];
@@ -745,6 +765,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
     constexpr int H = TL::H, S = TL::S, R = TL::R, PAIRS = S * R / 2 / NTT_THREADS;
     __shared__ u64 lds[TL::WORDS + 2 * TA::WORDS];
     u64 *twa = lds + TL::WORDS, *twa_sh = twa + TA::WORDS;
+    stagger_start<4, 8>(T.stagger);
     // 1-D grid over (limb slot, row tile, polynomial).  All polynomials of one (slot, tile) read the same
     // 2*S*R-word twiddle tile: they are made consecutive inside ONE XCD's queue (blocks b, b+8, ... share an
     // XCD under round-robin dispatch) so the tile is fetched over the fabric once and then hits in that L2.
@@ -1704,6 +1725,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_once(TailOnceArgs 
     using TL = RowT<LOGC>;
     constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
     __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
+    stagger_start<3, 10>(T.stagger);
     Row3Ctx c;
     c.lds = lds;
     c.twa = lds + TL::WORDS;
@@ -1854,6 +1876,7 @@ __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_
     using TL = RowT<LOGC>;
     constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
     __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
+    stagger_start<(INVP ? MK_INVP_WAVES : 3), (INVP ? 27 : 14)>(T.stagger);
     Row3Ctx c;
     c.lds = lds;
     c.twa = lds + TL::WORDS;

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
     constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
     constexpr int ND = NPARTS - 1;
     __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
+    stagger_start<MINW, 12>(T.stagger * a.n_clients);  // lifetime grows with the client loop: 12 units per client and resident
     Row3Ctx c;
     c.lds = lds;
     c.twa = lds + TL::WORDS;

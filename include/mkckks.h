@@ -94,6 +94,29 @@ int mkckks_dev_free(mkckks_ctx *c, void *d_ptr);
 int mkckks_upload(mkckks_ctx *c, void *d_dst, const void *h_src, size_t bytes);   /* synchronous */
 int mkckks_download(mkckks_ctx *c, void *h_dst, const void *d_src, size_t bytes); /* synchronous */
 
+/* ---- I/O pipeline of the server hosts (new; SURVEY.md 8f row f1: "removes the I/O wall") -----------------------
+ * The reference's server moves every ciphertext through the host, one at a time and synchronously, between
+ * Base64Decode + Serial::Deserialize and cc->ReEncrypt / cc->EvalAdd (server/src/changeCipherDomain.cpp:61-117,
+ * aggregateEncryptedWeights.cpp:18-30,54-119).  Here a host reads ciphertext payloads straight into PINNED buffers
+ * (mkckks_host_alloc) and enqueues them on the context's upload stream while it reads the next ones; results leave on
+ * a download stream (PCIe is full duplex).  Every copy gets a ticket (counting up from 1): mkckks_copy_done polls it,
+ * mkckks_copy_wait blocks on it (and on every earlier copy of the same direction).  Ordering against the compute
+ * stream is explicit: mkckks_fence_uploads makes the compute stream wait for every upload enqueued so far,
+ * mkckks_fence_compute makes the download stream wait for all compute enqueued so far.  Host buffers of an
+ * asynchronous copy must be pinned and stay untouched until the copy's ticket is done.  One host thread drives a
+ * context (reader threads only fill pinned buffers).
+ * mkckks_count_noncanonical: nothing in a client's file is trusted and the kernels assume canonical residues; counts
+ * the residues of d_ct u64[n_ct][2][nl][N] that are not below their limb's modulus (synchronous; 0 = accept). */
+int mkckks_host_alloc(mkckks_ctx *c, size_t bytes, void **h_out);
+int mkckks_host_free(mkckks_ctx *c, void *h_ptr);
+int mkckks_upload_async(mkckks_ctx *c, void *d_dst, const void *h_src_pinned, size_t bytes, uint64_t *ticket_out);
+int mkckks_download_async(mkckks_ctx *c, void *h_dst_pinned, const void *d_src, size_t bytes, uint64_t *ticket_out);
+int mkckks_copy_done(mkckks_ctx *c, uint64_t ticket, int *done_out);
+int mkckks_copy_wait(mkckks_ctx *c, uint64_t ticket);
+int mkckks_fence_uploads(mkckks_ctx *c);
+int mkckks_fence_compute(mkckks_ctx *c);
+int mkckks_count_noncanonical(mkckks_ctx *c, const uint64_t *d_ct, uint32_t n_ct, uint32_t nl, uint64_t *h_count);
+
 /* ---- transforms: DCRTPoly::SetFormat (OpenFHE ChineseRemainderTransformFTT)
  * d_polys is u64[n_polys][nl(+K)][N], transformed in place.  with_p != 0 means
  * each polynomial carries the K P-limbs after its nl Q-limbs. */

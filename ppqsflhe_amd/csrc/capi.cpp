@@ -161,6 +161,63 @@ int mkckks_download(mkckks_ctx *c, void *h, const void *d, size_t bytes) {
     });
 }
 
+int mkckks_host_alloc(mkckks_ctx *c, size_t bytes, void **h_out) {
+    return guarded([&] {
+        need(c && h_out, "null argument");
+        *h_out = c->eng->host_alloc(bytes);
+    });
+}
+int mkckks_host_free(mkckks_ctx *c, void *h) {
+    return guarded([&] {
+        need(c, "null context");
+        c->eng->host_free(h);
+    });
+}
+int mkckks_upload_async(mkckks_ctx *c, void *d, const void *h, size_t bytes, uint64_t *ticket_out) {
+    return guarded([&] {
+        need(c && (bytes == 0 || (d && h)), "null argument");
+        const uint64_t t = c->eng->upload_async(d, h, bytes);
+        if (ticket_out) *ticket_out = t;
+    });
+}
+int mkckks_download_async(mkckks_ctx *c, void *h, const void *d, size_t bytes, uint64_t *ticket_out) {
+    return guarded([&] {
+        need(c && (bytes == 0 || (d && h)), "null argument");
+        const uint64_t t = c->eng->download_async(h, d, bytes);
+        if (ticket_out) *ticket_out = t;
+    });
+}
+int mkckks_copy_done(mkckks_ctx *c, uint64_t ticket, int *done_out) {
+    return guarded([&] {
+        need(c && done_out, "null argument");
+        *done_out = c->eng->copy_done(ticket) ? 1 : 0;
+    });
+}
+int mkckks_copy_wait(mkckks_ctx *c, uint64_t ticket) {
+    return guarded([&] {
+        need(c, "null context");
+        c->eng->copy_wait(ticket);
+    });
+}
+int mkckks_fence_uploads(mkckks_ctx *c) {
+    return guarded([&] {
+        need(c, "null context");
+        c->eng->fence_uploads();
+    });
+}
+int mkckks_fence_compute(mkckks_ctx *c) {
+    return guarded([&] {
+        need(c, "null context");
+        c->eng->fence_compute();
+    });
+}
+int mkckks_count_noncanonical(mkckks_ctx *c, const uint64_t *d_ct, uint32_t n_ct, uint32_t nl, uint64_t *h_count) {
+    return guarded([&] {
+        need(c && h_count && (n_ct == 0 || d_ct), "null argument");
+        *h_count = c->eng->count_noncanonical(d_ct, n_ct, nl);
+    });
+}
+
 int mkckks_ntt_forward_batch(mkckks_ctx *c, uint64_t *d, uint32_t n_polys, uint32_t nl, int with_p) {
     return guarded([&] {
         need(c && d, "null argument");

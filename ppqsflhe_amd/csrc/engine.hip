@@ -488,6 +488,10 @@ Knobs Knobs::from_env() {
         const int v = std::atoi(e);
         if (v >= 0 && v <= 1000) k.stagger = (uint32_t)v;
     }
+    if (const char *e = std::getenv("MKCKKS_QSUM_PIPE")) {
+        const int v = std::atoi(e);
+        if (v >= 0 && v <= 2) k.qsum_pipe = v;
+    }
     k.generic_ntt = env_flag("MKCKKS_GENERIC_NTT", k.generic_ntt);
     k.no_pm = env_flag("MKCKKS_NO_PM", k.no_pm);
     k.no_fp64 = env_flag("MKCKKS_NO_FP64", k.no_fp64);
@@ -621,6 +625,12 @@ Engine::~Engine() {
                     (void *)d_rot_, (void *)d_ksi_})
         if (p) (void)hipFree(p);
     for (void *p : owned_) (void)hipFree(p);
+    if (up_stream_) {
+        (void)hipStreamDestroy(up_stream_);
+        (void)hipStreamDestroy(down_stream_);
+        for (uint32_t i = 0; i < COPY_RING; ++i) (void)hipEventDestroy(copy_ev_[i]);
+        (void)hipEventDestroy(ev_fence_);
+    }
     if (side_stream_) (void)hipStreamDestroy(side_stream_);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
@@ -656,6 +666,92 @@ void Engine::download(void *h, const void *d, size_t bytes) {
     need_device();
     MK_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream_));
     MK_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---- I/O pipeline -------------------------------------------------------------------
+void Engine::copy_streams() {
+    if (up_stream_) return;
+    MK_HIP(hipStreamCreateWithFlags(&up_stream_, hipStreamNonBlocking));
+    MK_HIP(hipStreamCreateWithFlags(&down_stream_, hipStreamNonBlocking));
+    for (uint32_t i = 0; i < COPY_RING; ++i) MK_HIP(hipEventCreateWithFlags(&copy_ev_[i], hipEventDisableTiming));
+    MK_HIP(hipEventCreateWithFlags(&ev_fence_, hipEventDisableTiming));
+}
+void *Engine::host_alloc(size_t bytes) {
+    need_device();
+    void *p = nullptr;
+    MK_HIP(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault));
+    return p;
+}
+void Engine::host_free(void *p) {
+    need_device();
+    if (p) MK_HIP(hipHostFree(p));
+}
+uint64_t Engine::enqueue_copy(void *dst, const void *src, size_t bytes, bool up) {
+    need_device();
+    copy_streams();
+    const uint64_t t = next_ticket_;
+    if (t > COPY_RING) {  // the ring slot's previous copy (ticket t - COPY_RING) must be over before its event is re-recorded
+        MK_HIP(hipEventSynchronize(copy_ev_[t % COPY_RING]));
+        done_ticket_ = std::max(done_ticket_, t - COPY_RING);
+    }
+    hipStream_t s = up ? up_stream_ : down_stream_;
+    MK_HIP(hipMemcpyAsync(dst, src, bytes, up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, s));
+    MK_HIP(hipEventRecord(copy_ev_[t % COPY_RING], s));
+    ++next_ticket_;
+    return t;
+}
+uint64_t Engine::upload_async(void *d, const void *h, size_t bytes) { return enqueue_copy(d, h, bytes, true); }
+uint64_t Engine::download_async(void *h, const void *d, size_t bytes) { return enqueue_copy(h, d, bytes, false); }
+bool Engine::copy_done(uint64_t ticket) {
+    need_device();
+    if (ticket == 0 || ticket >= next_ticket_) throw std::invalid_argument("unknown copy ticket");
+    if (ticket <= done_ticket_ || ticket + COPY_RING < next_ticket_) return true;  // slot already recycled: waited for then
+    const hipError_t e = hipEventQuery(copy_ev_[ticket % COPY_RING]);
+    if (e == hipErrorNotReady) return false;
+    MK_HIP(e);
+    return true;
+}
+void Engine::copy_wait(uint64_t ticket) {
+    need_device();
+    if (ticket == 0 || ticket >= next_ticket_) throw std::invalid_argument("unknown copy ticket");
+    if (ticket <= done_ticket_ || ticket + COPY_RING < next_ticket_) return;
+    MK_HIP(hipEventSynchronize(copy_ev_[ticket % COPY_RING]));
+}
+void Engine::fence_uploads() {
+    need_device();
+    if (!up_stream_) return;
+    MK_HIP(hipEventRecord(ev_fence_, up_stream_));
+    MK_HIP(hipStreamWaitEvent(stream_, ev_fence_, 0));
+}
+void Engine::fence_compute() {
+    need_device();
+    copy_streams();
+    MK_HIP(hipEventRecord(ev_fence_, stream_));
+    MK_HIP(hipStreamWaitEvent(down_stream_, ev_fence_, 0));
+}
+
+// residues at or above their modulus, counted per workgroup and added to *bad (untrusted ciphertext files: the kernels
+// assume canonical residues)
+__global__ void k_count_noncanonical(const u64 *ct, EwGeom g, const LimbConst *limb, uint32_t slots, unsigned long long *bad) {
+    EW_PROLOGUE(slots)
+    const u64 q = limb[limb_id_of(slot % g.nl, g.nl, g.L)].q;
+    const ulong2 v = ld2(ct + ((size_t)item * slots + slot) * g.n + idx);
+    const unsigned long long wx = __ballot(v.x >= q), wy = __ballot(v.y >= q);  // one atomic per wave, and only for bad data
+    if ((wx | wy) != 0 && (threadIdx.x & 63) == 0) atomicAdd(bad, (unsigned long long)(__popcll(wx) + __popcll(wy)));
+}
+uint64_t Engine::count_noncanonical(const u64 *ct, uint32_t n_ct, uint32_t nl) {
+    need_device();
+    check_nl(nl);
+    if (!n_ct) return 0;
+    unsigned long long *d_bad = reinterpret_cast<unsigned long long *>(workspace(1));
+    MK_HIP(hipMemsetAsync(d_bad, 0, 8, stream_));
+    EwGeom g{ps_.n, nl, ps_.L};
+    k_count_noncanonical<<<ew_grid(ps_.n, 2 * nl, n_ct), EW_THREADS, 0, stream_>>>(ct, g, d_limb_, 2 * nl, d_bad);
+    MK_HIP(hipGetLastError());
+    unsigned long long h = 0;
+    MK_HIP(hipMemcpyAsync(&h, d_bad, 8, hipMemcpyDeviceToHost, stream_));
+    MK_HIP(hipStreamSynchronize(stream_));
+    return h;
 }
 
 void Engine::check_nl(uint32_t nl) const {
@@ -1622,6 +1718,20 @@ static void launch_qsum3_fp(const QSumArgs &a, const NttTables &T, uint32_t npar
     }
 }
 
+template <int LOGC, int MINW>
+static void launch_qsum3p_fp(const QSumArgs &a, const NttTables &T, uint32_t nparts, hipStream_t s) {
+    const uint32_t tiles = (1u << T.log_r1) / RowT<LOGC>::ROWS;
+    const dim3 grid(tiles * a.nsel * a.cnt);
+    switch (nparts) {
+        case 2: k_qsum3p_fp<2, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 3: k_qsum3p_fp<3, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 4: k_qsum3p_fp<4, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 5: k_qsum3p_fp<5, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        case 6: k_qsum3p_fp<6, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
+        default: throw std::invalid_argument("pipelined sum kernel: 2..6 key-switch digits");
+    }
+}
+
 // per Q limb: P mod q, (P mod q)/q, P^-1 mod q, (P^-1 mod q)/q as doubles (fp64-class limbs; zeros elsewhere)
 const u64 *Engine::p_doubles() {
     auto it = vec_cache_.find("p_doubles");
@@ -1746,7 +1856,15 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
             }
             QSumArgs qa{dig, convsum, ct0, evk0, out + (size_t)b0 * ct_words, pq, ct_cstride, ct_words, evk_words, ct_words,
                         gc, cnt, nl, ext, D, ps_.alpha, fp_mask, (uint32_t)__builtin_popcountll(fp_mask), g0 != 0 ? 1u : 0u};
-            if (wide_rows) launch_qsum3_fp<3, 3>(qa, tabs_, nparts, main);
+            if (knobs_.qsum_pipe && nparts >= 2 && knobs_.qsum_geom == 3) {  // operand loads software-pipelined
+                if (wide_rows) {
+                    if (knobs_.qsum_pipe == 2) launch_qsum3p_fp<3, 2>(qa, tabs_, nparts, main);
+                    else launch_qsum3p_fp<3, 3>(qa, tabs_, nparts, main);
+                } else {
+                    if (knobs_.qsum_pipe == 2) launch_qsum3p_fp<2, 2>(qa, tabs_, nparts, main);
+                    else launch_qsum3p_fp<2, 3>(qa, tabs_, nparts, main);
+                }
+            } else if (wide_rows) launch_qsum3_fp<3, 3>(qa, tabs_, nparts, main);
             else if (knobs_.qsum_geom == 2) launch_qsum_fp<4>(qa, tabs_, nparts, main);
             else if (knobs_.qsum_geom == 4) launch_qsum3_fp<2, 2>(qa, tabs_, nparts, main);
             else launch_qsum3_fp<2, 3>(qa, tabs_, nparts, main);

@@ -58,6 +58,7 @@ struct Knobs {
                                  // the summed ModDown conversions per group: 8 is +2.7 % against 4, 2 is -6.6 %)
     uint32_t stagger = 0;        // MKCKKS_STAGGER: start-phase stagger of each pass's first generation of workgroups, percent of
                                  // the built-in steps (ntt_radix.hpp: stagger_start); 0 = all workgroups start together
+    int qsum_pipe = 0;           // MKCKKS_QSUM_PIPE: 1 / 2 = k_qsum3p_fp (operand loads software-pipelined) at 3 / 2 waves per SIMD
     int qsum_geom = 3;           // MKCKKS_QSUM_GEOM: 3 = three-round k_qsum3_fp (3 waves per SIMD), 2 = two-round k_qsum_fp
     bool generic_ntt = false;    // MKCKKS_GENERIC_NTT=1: LDS-stage kernels for both passes
     bool no_pm = false;          // MKCKKS_NO_PM=1: Shoup butterflies on the integer limbs instead of the pseudo-Mersenne ones
@@ -91,6 +92,18 @@ public:
     void dev_free(void *p);
     void upload(void *d, const void *h, size_t bytes);
     void download(void *h, const void *d, size_t bytes);
+    // I/O pipeline of the hosts: pinned host buffers and copies on the context's two copy streams (one per direction,
+    // PCIe is full duplex), ordered against the compute stream by fences; every copy gets a ticket the host can poll
+    void *host_alloc(size_t bytes);
+    void host_free(void *p);
+    uint64_t upload_async(void *d, const void *h, size_t bytes);
+    uint64_t download_async(void *h, const void *d, size_t bytes);
+    bool copy_done(uint64_t ticket);
+    void copy_wait(uint64_t ticket);
+    void fence_uploads();   // compute stream: wait for every upload enqueued so far
+    void fence_compute();   // download stream: wait for all compute enqueued so far
+    // residues of ciphertexts u64[n_ct][2][nl][N] that are not below their limb's modulus (0 = all canonical); synchronous
+    uint64_t count_noncanonical(const u64 *ct, uint32_t n_ct, uint32_t nl);
 
     // transforms, in place on u64[n_polys][ext][N]; ext = nl (+K when with_p)
     void ntt_forward(u64 *d, uint32_t n_polys, uint32_t nl, bool with_p);
@@ -168,6 +181,14 @@ private:
     u64 *d_tw_ = nullptr, *d_tw_sh_ = nullptr, *d_itw_ = nullptr, *d_itw_sh_ = nullptr;
     u64 *d_twb_ = nullptr, *d_itwb_ = nullptr;  // packed round-B tables of the row kernels (NttTables::twb)
     std::vector<uint8_t> fp_of_;  // per limb id: 1 = fp64 kernel instance
+    // copies: tickets count up from 1; ticket t's completion event is ring slot t % COPY_RING
+    static constexpr uint32_t COPY_RING = 64;
+    uint64_t enqueue_copy(void *dst, const void *src, size_t bytes, bool up);
+    void copy_streams();
+    hipStream_t up_stream_ = nullptr, down_stream_ = nullptr;
+    hipEvent_t copy_ev_[COPY_RING] = {};
+    hipEvent_t ev_fence_ = nullptr;
+    uint64_t next_ticket_ = 1, done_ticket_ = 0;  // every ticket <= done_ticket_ is known complete
     hipStream_t side_stream_ = nullptr;  // second client lane of reencrypt_sum
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     bool skip_rows_ = false;  // modup_core: leave the row pass of the converted digits to the fused kernels

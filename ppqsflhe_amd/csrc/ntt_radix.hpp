@@ -600,7 +600,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_icol_sum(const u64 *pc, u64 
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2;
     const int c = threadIdx.x % S, j = threadIdx.x / S;
     const size_t off = ((size_t)poly * K + k) * n + blockIdx.x * S + c;
-    const u64 *itw = T.itw + (size_t)id * n, *itw_sh = T.itw_sh + (size_t)id * n;
+    const u64 *itw0 = T.itw + (size_t)id * n, *itw_sh0 = T.itw_sh + (size_t)id * n;
     const u64 sc = scale[id], sc_sh = scale_sh[id];
     u64 acc[H];
 #pragma unroll
@@ -609,8 +609,15 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_icol_sum(const u64 *pc, u64 
     for (uint32_t cl = 0; cl < n_clients; ++cl) {
         const u64 *src = pc + (size_t)cl * in_cstride + off;
         u64 x[H], w[H - 1], wp[H - 1];
+        // nothing but the sums is meant to live across the client loop: left alone the compiler computes the H load
+        // offsets and loads the 2 (H - 1) round-B twiddles (they do not depend on the client) once in front of the loop
+        // and keeps ~90 registers alive across it (52 spilled at 3 waves per SIMD).  Values that are opaque per
+        // iteration are recomputed / re-read where they are used (L1 / L2 hits).
+        uint32_t r2v = r2;
+        const u64 *itw = itw0, *itw_sh = itw_sh0;
+        asm volatile("" : "+s"(r2v), "+s"(itw), "+s"(itw_sh));
 #pragma unroll
-        for (int kk = 0; kk < H; ++kk) x[kk] = ld_pass(src + (size_t)(H * j + kk) * r2);
+        for (int kk = 0; kk < H; ++kk) x[kk] = ld_pass(src + (uint32_t)(H * j + kk) * r2v);
         load_round_twiddles<LOG_H>(itw, itw_sh, (uint32_t)(H + j), w, wp);
         radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
         if (cl) __syncthreads();  // the previous client's exchange is read out
@@ -1423,7 +1430,26 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T,
 struct Row3Ctx {
     u64 *lds, *twa, *twa_sh, *twb, *twb_sh;
     int g, t;  // row of the tile, thread inside the row
+    // round-C twiddles parked in LDS by kernels that transform many polynomials per workgroup and are short of registers
+    // (row3_park_c_twiddles): pair i of thread tid at twc[i * NTT_THREADS + tid]
+    ulong2 *twc = nullptr;
 };
+// park / fetch this thread's round-C twiddles (wave-private LDS words: a thread only reads what it wrote)
+template <int LOGC>
+MK_D void row3_park_c_twiddles(const Row3Ctx &c, const u64 (&wc)[7], const u64 (&wpc)[7]) {
+#pragma unroll
+    for (int i = 0; i < (LOGC == 3 ? 7 : 6); ++i) c.twc[i * NTT_THREADS + threadIdx.x] = ulong2{wc[i], wpc[i]};
+}
+template <int LOGC>
+MK_D void row3_fetch_c_twiddles(const Row3Ctx &c, u64 (&wc)[7], u64 (&wpc)[7]) {
+#pragma unroll
+    for (int i = 0; i < (LOGC == 3 ? 7 : 6); ++i) {
+        const ulong2 t = c.twc[i * NTT_THREADS + threadIdx.x];
+        wc[i] = t.x;
+        wpc[i] = t.y;
+    }
+    if (LOGC != 3) wc[6] = wpc[6] = 0;
+}
 // stage the round-A / round-B twiddles of the tile's 4 rows (cooperative; the caller synchronises the workgroup)
 template <int LOGC>
 MK_D void row3_stage_twiddles(const Row3Ctx &c, const u64 *tw, const u64 *tw_sh, uint32_t base0) {
@@ -1462,8 +1488,8 @@ MK_D void row3_load_c_twiddles(const u64 *tw, const u64 *tw_sh, uint32_t base, i
 }
 // forward transform of this thread's row: x[k] = word t + TPR k on entry; on exit x[k] = word 8 t + k in the lazy
 // range of the arithmetic
-template <int AR, int LOGC>
-MK_D void row3_forward(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], const u64 (&wpc)[7], const LimbConst &lc) {
+template <int AR, int LOGC, bool C_PARKED = false>
+MK_D void row3_forward(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc_in)[7], const u64 (&wpc_in)[7], const LimbConst &lc) {
     using TL = RowT<LOGC>;
     constexpr int S = TL::ROWS, TPR = TL::TPR, C = TL::C;
     const int a = c.t / C, cc = c.t % C;
@@ -1496,6 +1522,16 @@ MK_D void row3_forward(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], const 
     wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = c.lds[TL::at(c.g, 8 * c.t + k)];
+    u64 wc[7], wpc[7];
+    if (C_PARKED) {
+        row3_fetch_c_twiddles<LOGC>(c, wc, wpc);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            wc[i] = wc_in[i];
+            wpc[i] = wpc_in[i];
+        }
+    }
     if (LOGC == 3) {
         radix_forward_any<3, AR>(x, wc, wpc, lc);
     } else {  // two radix-4 groups: words 8t..8t+3 and 8t+4..8t+7

@@ -1,0 +1,379 @@
+// iopipe.hpp -- I/O pipeline of the server hosts for binary (MKWS) envelopes (second half).
+//
+// The reference's server programs move every ciphertext through the host one at a time and synchronously: file -> JSON
+// string -> Base64Decode -> Serial::Deserialize -> OpenFHE call -> Serialize -> Base64Encode -> JSON -> file
+// (server/src/changeCipherDomain.cpp:61-123, server/src/aggregateEncryptedWeights.cpp:18-30,54-119).  With the
+// arithmetic on the GPU at ~28 k ciphertexts/s the host side is the wall: a 12 MiB ciphertext is used once, so the
+// PCIe link (~50 GB/s, ~4 k ct/s) is the ceiling of a host-resident deployment and every extra copy on the host counts.
+// Here, for MKWS envelopes:
+//   * the file is INDEXED, not loaded: skeleton JSON + (offset, size) of every ciphertext container;
+//   * reader threads pread() ciphertext payloads straight into a ring of PINNED slots (mkckks_host_alloc); the main
+//     thread enqueues each filled slot on the context's upload stream (mkckks_upload_async) and recycles it when its
+//     ticket is done -- reading file k+1 overlaps the upload of file k, no pageable staging copy in between;
+//   * residues are range-checked on the DEVICE (mkckks_count_noncanonical) instead of in a host loop, headers on the host;
+//   * results come back through pinned slots on the download stream and are written with pwrite() by writer threads at
+//     offsets known in advance -- the output file is byte-identical to what write_envelope() produces.
+// One host thread drives the context; the other threads only touch file descriptors and pinned memory.
+#pragma once
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+#include "hostlib.hpp"
+
+namespace mkh {
+
+inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct BlobRef {
+    uint64_t offset = 0, size = 0;  // the container (BlobHeader + residues) inside the file
+};
+// an MKWS file without its blobs: the skeleton document (ciphertext fields hold "@<index>") and where every blob sits
+struct EnvelopeIndex {
+    Json doc;
+    std::vector<BlobRef> blobs;
+    int fd = -1;
+    EnvelopeIndex() = default;
+    EnvelopeIndex(const EnvelopeIndex &) = delete;
+    EnvelopeIndex &operator=(const EnvelopeIndex &) = delete;
+    EnvelopeIndex(EnvelopeIndex &&o) noexcept : doc(std::move(o.doc)), blobs(std::move(o.blobs)), fd(o.fd) { o.fd = -1; }
+    ~EnvelopeIndex() {
+        if (fd >= 0) ::close(fd);
+    }
+};
+
+inline void pread_all(int fd, void *dst, size_t bytes, uint64_t offset) {
+    char *p = static_cast<char *>(dst);
+    while (bytes) {
+        const ssize_t r = ::pread(fd, p, bytes, (off_t)offset);
+        if (r <= 0) throw std::runtime_error("binary envelope: short read");
+        p += r;
+        offset += (uint64_t)r;
+        bytes -= (size_t)r;
+    }
+}
+inline void pwrite_all(int fd, const void *src, size_t bytes, uint64_t offset) {
+    const char *p = static_cast<const char *>(src);
+    while (bytes) {
+        const ssize_t r = ::pwrite(fd, p, bytes, (off_t)offset);
+        if (r <= 0) throw std::runtime_error("cannot write output file");
+        p += r;
+        offset += (uint64_t)r;
+        bytes -= (size_t)r;
+    }
+}
+
+// false: not an MKWS file (the caller takes the JSON path).  Every size field is checked against the file size, as in
+// read_envelope(); blob indices in the skeleton are checked to be a permutation-free subset of the blob table.
+inline bool index_envelope(const std::string &path, EnvelopeIndex &out) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + path);
+    out.fd = fd;
+    struct stat st;
+    if (::fstat(fd, &st) != 0) throw std::runtime_error("cannot stat " + path);
+    const uint64_t file_size = (uint64_t)st.st_size;
+    char head[16];
+    if (file_size < 24 || (pread_all(fd, head, 16, 0), std::memcmp(head, "MKWS", 4) != 0)) {
+        ::close(fd);
+        out.fd = -1;
+        return false;
+    }
+    auto fail = [&](const char *why) { throw std::runtime_error(std::string("binary envelope: ") + why); };
+    uint32_t version;
+    uint64_t skel_len;
+    std::memcpy(&version, head + 4, 4);
+    std::memcpy(&skel_len, head + 8, 8);
+    if (version != 1) fail("unsupported version");
+    uint64_t pos = 16;
+    if (skel_len > file_size - pos) fail("bad skeleton size");
+    std::string skel(skel_len, '\0');
+    if (skel_len) pread_all(fd, &skel[0], skel_len, pos);
+    pos += skel_len;
+    uint64_t n_blobs = 0;
+    if (file_size - pos < 8) fail("truncated");
+    pread_all(fd, &n_blobs, 8, pos);
+    pos += 8;
+    if (n_blobs > (file_size - pos) / 8) fail("bad blob count");
+    out.blobs.resize(n_blobs);
+    for (BlobRef &b : out.blobs) {
+        uint64_t sz = 0;
+        if (file_size - pos < 8) fail("truncated blob table");
+        pread_all(fd, &sz, 8, pos);
+        pos += 8;
+        if (sz > file_size - pos) fail("bad blob size");
+        b.offset = pos;
+        b.size = sz;
+        pos += sz;
+    }
+    out.doc = Json::parse(skel);
+    std::vector<bool> used(out.blobs.size(), false);
+    for_each_ct_field(out.doc, [&](Json &field) {
+        const std::string &ref = field.as_string();
+        if (ref.size() < 2 || ref[0] != '@') fail("ciphertext field without a blob index");
+        const size_t i = std::stoull(ref.substr(1));
+        if (i >= used.size() || used[i]) fail("blob index out of range or reused");
+        used[i] = true;
+    });
+    return true;
+}
+inline size_t blob_index(const std::string &ref) { return std::stoull(ref.substr(1)); }
+
+// run fn(i) for i in [0, n) on up to `threads` threads; the first exception is rethrown on the caller's thread
+template <typename F>
+inline void parallel_for(size_t n, unsigned threads, F &&fn) {
+    threads = (unsigned)std::min<size_t>(std::max(1u, threads), n ? n : 1);
+    std::atomic<size_t> next{0};
+    std::exception_ptr err;
+    std::mutex m;
+    auto body = [&] {
+        try {
+            for (size_t i; (i = next.fetch_add(1)) < n;) fn(i);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(m);
+            if (!err) err = std::current_exception();
+            next.store(n);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(body);
+    body();
+    for (std::thread &t : pool) t.join();
+    if (err) std::rethrow_exception(err);
+}
+
+inline unsigned io_threads() {
+    if (const char *e = std::getenv("MKCKKS_IO_THREADS")) return (unsigned)std::max(1, std::atoi(e));
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::max(2u, std::min(8u, hw ? hw : 4u));
+}
+
+// A ring of pinned slots shared by the loader and the writer.
+class PinnedRing {
+public:
+    PinnedRing(Session &s, size_t slot_bytes, unsigned n_slots) : s_(s), slot_bytes_(slot_bytes) {
+        void *p = nullptr;
+        Session::check(mkckks_host_alloc(s.ctx(), slot_bytes * n_slots, &p));
+        base_ = static_cast<char *>(p);
+        n_ = n_slots;
+    }
+    ~PinnedRing() {
+        if (base_) mkckks_host_free(s_.ctx(), base_);
+    }
+    PinnedRing(const PinnedRing &) = delete;
+    PinnedRing &operator=(const PinnedRing &) = delete;
+    char *slot(unsigned i) const { return base_ + (size_t)i * slot_bytes_; }
+    unsigned count() const { return n_; }
+    size_t slot_bytes() const { return slot_bytes_; }
+
+private:
+    Session &s_;
+    size_t slot_bytes_;
+    char *base_ = nullptr;
+    unsigned n_ = 0;
+};
+
+// one ciphertext container to bring into HBM: header to `hdr`, residues to d_dst
+struct LoadJob {
+    int fd;
+    BlobRef blob;
+    uint64_t *d_dst;
+    BlobHeader hdr;
+};
+
+// read every job's payload into a pinned slot (reader threads) and upload it (this thread); returns when every upload
+// has completed.  payload_bytes: what every container must carry after its header (all ciphertexts of a round have one
+// shape; a container of another size is refused).
+inline void load_ciphertexts(Session &s, PinnedRing &ring, std::vector<LoadJob> &jobs, size_t payload_bytes, unsigned threads) {
+    if (jobs.empty()) return;
+    if (payload_bytes > ring.slot_bytes()) throw std::logic_error("pinned slot smaller than a ciphertext");
+    std::mutex m;
+    std::condition_variable cv_free, cv_filled;
+    std::deque<unsigned> free_slots;
+    std::deque<std::pair<unsigned, size_t>> filled;  // (slot, job)
+    for (unsigned i = 0; i < ring.count(); ++i) free_slots.push_back(i);
+    std::atomic<size_t> next{0};
+    std::exception_ptr err;
+    bool stop = false;
+    auto reader = [&] {
+        try {
+            for (size_t j; (j = next.fetch_add(1)) < jobs.size();) {
+                unsigned slot;
+                {
+                    std::unique_lock<std::mutex> g(m);
+                    cv_free.wait(g, [&] { return stop || !free_slots.empty(); });
+                    if (stop) return;
+                    slot = free_slots.front();
+                    free_slots.pop_front();
+                }
+                LoadJob &job = jobs[j];
+                if (job.blob.size != sizeof(BlobHeader) + payload_bytes) throw std::runtime_error("ciphertext blob has the wrong size");
+                pread_all(job.fd, &job.hdr, sizeof(BlobHeader), job.blob.offset);
+                pread_all(job.fd, ring.slot(slot), payload_bytes, job.blob.offset + sizeof(BlobHeader));
+                {
+                    std::lock_guard<std::mutex> g(m);
+                    filled.emplace_back(slot, j);
+                }
+                cv_filled.notify_one();
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> g(m);
+            if (!err) err = std::current_exception();
+            stop = true;
+            cv_filled.notify_all();
+            cv_free.notify_all();
+        }
+    };
+    std::vector<std::thread> pool;
+    const unsigned nthr = (unsigned)std::min<size_t>(std::max(1u, threads), jobs.size());
+    for (unsigned t = 0; t < nthr; ++t) pool.emplace_back(reader);
+    std::deque<std::pair<uint64_t, unsigned>> in_flight;  // (ticket, slot), in ticket order
+    size_t uploaded = 0;
+    std::exception_ptr main_err;
+    try {
+        while (uploaded < jobs.size() || !in_flight.empty()) {
+            std::pair<unsigned, size_t> got{0, 0};
+            bool have = false;
+            {
+                std::unique_lock<std::mutex> g(m);
+                if (stop) break;
+                if (filled.empty() && uploaded < jobs.size())
+                    cv_filled.wait_for(g, std::chrono::microseconds(in_flight.empty() ? 2000 : 50));
+                if (!filled.empty()) {
+                    got = filled.front();
+                    filled.pop_front();
+                    have = true;
+                }
+            }
+            if (have) {
+                uint64_t ticket = 0;
+                Session::check(mkckks_upload_async(s.ctx(), jobs[got.second].d_dst, ring.slot(got.first), payload_bytes, &ticket));
+                in_flight.emplace_back(ticket, got.first);
+                ++uploaded;
+            }
+            while (!in_flight.empty()) {  // uploads complete in ticket order
+                int done = 0;
+                if (uploaded == jobs.size() && !have) Session::check(mkckks_copy_wait(s.ctx(), in_flight.front().first)), done = 1;
+                else Session::check(mkckks_copy_done(s.ctx(), in_flight.front().first, &done));
+                if (!done) break;
+                {
+                    std::lock_guard<std::mutex> g(m);
+                    free_slots.push_back(in_flight.front().second);
+                }
+                cv_free.notify_one();
+                in_flight.pop_front();
+            }
+        }
+    } catch (...) {
+        main_err = std::current_exception();
+    }
+    {
+        std::lock_guard<std::mutex> g(m);
+        stop = stop || main_err != nullptr;
+    }
+    cv_free.notify_all();
+    for (std::thread &t : pool) t.join();
+    if (main_err) std::rethrow_exception(main_err);
+    if (err) std::rethrow_exception(err);
+}
+
+// header checks of validate_ct() for a container that went straight to the device; residues are checked there
+inline Ciphertext meta_of(const BlobHeader &h, const Session &s) {
+    if (std::memcmp(h.magic, "MKCK", 4) || h.version != 1 || h.kind != KIND_CT)
+        throw std::runtime_error("not a mkckks ciphertext blob");
+    if (h.ring_dim != s.N() || h.parts != 2) throw std::runtime_error("ciphertext does not match the CryptoContext");
+    Ciphertext ct;
+    ct.nl = h.limbs; ct.level = h.level; ct.noise_deg = h.noise_deg; ct.scale = h.scale; ct.slots = h.slots;
+    const uint32_t L = s.L();
+    if (ct.nl < 1 || ct.nl > L) throw std::runtime_error("ciphertext: limb count outside [1, L]");
+    if (ct.level != L - ct.nl) throw std::runtime_error("ciphertext: level does not match its limb count");
+    if (ct.noise_deg != 1 && ct.noise_deg != 2) throw std::runtime_error("ciphertext: noiseScaleDeg must be 1 or 2");
+    if (!(ct.scale > 0) || !std::isfinite(ct.scale)) throw std::runtime_error("ciphertext: bad scaling factor");
+    if (ct.slots > s.N() / 2) throw std::runtime_error("ciphertext: slot count exceeds N/2");
+    return ct;
+}
+
+inline BlobHeader header_of(const Ciphertext &meta, uint32_t ring_dim) {
+    BlobHeader h{};
+    std::memcpy(h.magic, "MKCK", 4);
+    h.version = 1; h.kind = KIND_CT; h.ring_dim = ring_dim; h.limbs = meta.nl; h.parts = 2;
+    h.level = meta.level; h.noise_deg = meta.noise_deg; h.scale = meta.scale; h.slots = meta.slots;
+    return h;
+}
+
+// Write an MKWS envelope whose B ciphertexts [B][2][meta.nl][N] sit in HBM: the skeleton is `doc` with the item fields
+// replaced by "@<item index>" (items are in for_each_ct_field order: per layer mean, std_dev, values...), the blobs are
+// header + residues.  Downloads go through the ring on the download stream; writer threads pwrite() at offsets fixed by
+// the skeleton.  Byte-identical to store_agg_items() + write_envelope(.., binary = true).
+inline void write_envelope_from_device(Session &s, PinnedRing &ring, const std::vector<AggItem> &items, const uint64_t *d_cts,
+                                       const Ciphertext &meta, Json doc, const std::string &path, unsigned threads) {
+    const uint32_t N = s.N();
+    const size_t B = items.size(), owords = (size_t)2 * meta.nl * N, payload = owords * 8;
+    if (payload > ring.slot_bytes()) throw std::logic_error("pinned slot smaller than a ciphertext");
+    for (size_t b = 0; b < B; ++b) {
+        Json &lay = doc["weights_summary"].a[items[b].out_layer];
+        Json ref("@" + std::to_string(b));
+        if (items[b].field == 0) lay["mean"] = ref;
+        else if (items[b].field == 1) lay["std_dev"] = ref;
+        else lay["values"].a[items[b].idx] = ref;
+    }
+    {   // the writer's blob order is for_each_ct_field order: it must be the item order
+        size_t k = 0;
+        for_each_ct_field(doc, [&](Json &field) {
+            if (field.as_string() != "@" + std::to_string(k)) throw std::logic_error("envelope fields out of item order");
+            ++k;
+        });
+        if (k != B) throw std::logic_error("envelope holds ciphertext fields that are not aggregate items");
+    }
+    std::string text;
+    doc.dump(text, 2);
+    const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) throw std::runtime_error("cannot write " + path);
+    struct Closer {
+        int fd;
+        ~Closer() { ::close(fd); }
+    } closer{fd};
+    const uint32_t version = 1;
+    const uint64_t skel_len = text.size(), n_blobs = B, blob_size = sizeof(BlobHeader) + payload;
+    std::string head("MKWS", 4);
+    head.append(reinterpret_cast<const char *>(&version), 4);
+    head.append(reinterpret_cast<const char *>(&skel_len), 8);
+    head += text;
+    head.append(reinterpret_cast<const char *>(&n_blobs), 8);
+    const uint64_t blobs0 = head.size();
+    if (::ftruncate(fd, (off_t)(blobs0 + B * (8 + blob_size))) != 0) throw std::runtime_error("cannot size " + path);
+    pwrite_all(fd, head.data(), head.size(), 0);
+    const BlobHeader h = header_of(meta, N);
+    Session::check(mkckks_fence_compute(s.ctx()));
+    // rounds of ring.count() ciphertexts: download all of a round, then write them in parallel while ... the next round's
+    // downloads wait for the slots; with B <= slots (the usual case) it is one round
+    for (size_t b0 = 0; b0 < B; b0 += ring.count()) {
+        const size_t nb = std::min<size_t>(ring.count(), B - b0);
+        std::vector<uint64_t> tickets(nb);
+        for (size_t i = 0; i < nb; ++i)
+            Session::check(mkckks_download_async(s.ctx(), ring.slot((unsigned)i), d_cts + (b0 + i) * owords, payload, &tickets[i]));
+        std::mutex mt;  // the context is driven by one thread at a time: ticket waits are serialised
+        parallel_for(nb, threads, [&](size_t i) {
+            {
+                std::lock_guard<std::mutex> g(mt);
+                Session::check(mkckks_copy_wait(s.ctx(), tickets[i]));
+            }
+            const uint64_t at = blobs0 + (b0 + i) * (8 + blob_size);
+            char pre[8 + sizeof(BlobHeader)];
+            std::memcpy(pre, &blob_size, 8);
+            std::memcpy(pre + 8, &h, sizeof h);
+            pwrite_all(fd, pre, sizeof pre, at);
+            pwrite_all(fd, ring.slot((unsigned)i), payload, at + sizeof pre);
+        });
+    }
+}
+
+}  // namespace mkh

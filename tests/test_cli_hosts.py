@@ -381,6 +381,67 @@ def test_server_round_n_clients_equals_the_per_client_programs(tmp_path, n):
 
 
 @pytest.mark.gpu
+def test_server_round_io_pipeline_writes_the_same_bytes(tmp_path):
+    """SURVEY 8f f1, second half: binary (MKWS) envelopes go through the I/O pipeline of host/iopipe.hpp -- indexed files,
+    reader threads into pinned slots, asynchronous uploads (mkckks_upload_async), range check on the device, results
+    written with pwrite() from pinned slots -- instead of the synchronous path (read_envelope -> decode_ct -> validate_ct
+    -> mkckks_upload; the reference's shape: changeCipherDomain.cpp:61-117, aggregateEncryptedWeights.cpp:54-119).  Both
+    must write byte-identical aggregate and --back files; a residue at or above its modulus is refused on both."""
+    n = 4
+    cc = _small_cc(tmp_path)
+    rng = np.random.default_rng(91)
+
+    def ok(r):
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r
+
+    # 3 layers -> 2 + 2 + 2 + (3 + 1 + 0) = 10 ciphertexts per client: more than one pass of a small slot ring
+    vals = [[("dense", rng.uniform(-0.3, 0.3, 3 * 8192 - 5)), ("bias", rng.uniform(-0.3, 0.3, 7)), ("empty", [])] for _ in range(n)]
+    for c in range(n):
+        ok(run("keyGen", cc, tmp_path / f"pk{c}", tmp_path / f"sk{c}"))
+        ok(run("encryptModelWeights", cc, tmp_path / f"pk{c}", _weights(tmp_path, f"w{c}.json", vals[c]), tmp_path / f"enc{c}.mkws"))
+        assert open(tmp_path / f"enc{c}.mkws", "rb").read(4) == b"MKWS"
+    target = n - 1
+    args, back_a, back_b = [], [], []
+    for c in range(n - 1):
+        ok(run("REkeyGen", cc, tmp_path / f"sk{c}", tmp_path / f"pk{target}", tmp_path / f"rk{c}"))
+        args += [tmp_path / f"rk{c}", tmp_path / f"enc{c}.mkws"]
+    ok(run("REkeyGen", cc, tmp_path / f"sk{target}", tmp_path / "pk0", tmp_path / "rkback0"))
+    back_a = ["--back", tmp_path / "rkback0", tmp_path / "backA.mkws"]
+    back_b = ["--back", tmp_path / "rkback0", tmp_path / "backB.mkws"]
+    ra = ok(run("serverRound", cc, tmp_path / "aggA.mkws", "-", tmp_path / f"enc{target}.mkws", *args, *back_a,
+                env={"MKCKKS_SYNC_IO": "1"}))
+    rb = ok(run("serverRound", cc, tmp_path / "aggB.mkws", "-", tmp_path / f"enc{target}.mkws", *args, *back_b,
+                env={"MKCKKS_IO_THREADS": "3"}))
+    assert "[round] timing:" in rb.stdout and "[round] timing:" not in ra.stdout
+    assert open(tmp_path / "aggA.mkws", "rb").read() == open(tmp_path / "aggB.mkws", "rb").read()
+    assert open(tmp_path / "backA.mkws", "rb").read() == open(tmp_path / "backB.mkws", "rb").read()
+    # the aggregate decrypts to the mean
+    ok(run("decryptModelWeights", cc, tmp_path / f"sk{target}", tmp_path / "aggB.mkws", tmp_path / "dec.json"))
+    dec = json.load(open(tmp_path / "dec.json"))["weights_summary"]
+    mean = np.mean([np.asarray(vals[c][0][1]) for c in range(n)], axis=0)
+    assert np.abs(np.array(dec[0]["values"]) - mean).max() < 2.0 ** -25
+    # every client re-keyed (no "-"), one I/O thread
+    rc = ok(run("serverRound", cc, tmp_path / "aggC.mkws", *args, env={"MKCKKS_IO_THREADS": "1"}))
+    rd = ok(run("serverRound", cc, tmp_path / "aggD.mkws", *args, env={"MKCKKS_SYNC_IO": "1"}))
+    assert open(tmp_path / "aggC.mkws", "rb").read() == open(tmp_path / "aggD.mkws", "rb").read()
+    assert "[round] timing:" in rc.stdout and rd.returncode == 0
+    # a residue that is not below its modulus: both paths refuse the file (the pipelined one after the device-side check)
+    raw = bytearray(open(tmp_path / "enc0.mkws", "rb").read())
+    skel_len = int.from_bytes(raw[8:16], "little")
+    first_blob = 16 + skel_len + 8 + 8            # magic/version/skeleton size, skeleton, blob count, first blob size
+    raw[first_blob + 48 + 8 * 17:first_blob + 48 + 8 * 18] = (2 ** 64 - 1).to_bytes(8, "little")
+    open(tmp_path / "bad.mkws", "wb").write(raw)
+    for env in ({"MKCKKS_SYNC_IO": "1"}, {}):
+        r = run("serverRound", cc, tmp_path / "x.mkws", tmp_path / "rk0", tmp_path / "bad.mkws", "-", tmp_path / f"enc{target}.mkws", env=env)
+        assert r.returncode == 1 and "residue not below its modulus" in r.stderr, r.stdout + r.stderr
+    # a truncated file
+    open(tmp_path / "trunc.mkws", "wb").write(bytes(raw[:len(raw) // 2]))
+    r = run("serverRound", cc, tmp_path / "x.mkws", tmp_path / "rk0", tmp_path / "trunc.mkws", "-", tmp_path / f"enc{target}.mkws")
+    assert r.returncode == 1
+
+
+@pytest.mark.gpu
 def test_server_round_sends_the_aggregate_back_to_every_client(tmp_path):
     """The last leg of the round (orchestration/server_fns.sh:76-80, run.sh:42): the aggregate, which lives in the target
     client's key domain at one limb fewer, is re-encrypted into each other client's domain.  `serverRound ... --back`

@@ -481,6 +481,10 @@ def test_reencrypt_sum(ctxs, name, nl, C, B):
                                  {"MKCKKS_NO_PM": "1"},           # Shoup butterflies on q_0 and the P limbs
                                  {"MKCKKS_NO_PM": "1", "MKCKKS_QSUM": "0"},
                                  {"MKCKKS_QSUM_GEOM": "4"},       # three-round k_qsum3_fp at 2 waves per SIMD
+                                 {"MKCKKS_QSUM_PIPE": "1"},       # k_qsum3p_fp: operand loads software-pipelined, 3 waves
+                                 {"MKCKKS_QSUM_PIPE": "2"},       # ... 2 waves, own-digit tiles a whole phase ahead
+                                 {"MKCKKS_QSUM_PIPE": "1", "MKCKKS_QSUM_GROUP": "2"},
+                                 {"MKCKKS_STAGGER": "100"},       # start-phase stagger of every pass's first generation
                                  {"MKCKKS_NO_FP64": "1"},         # integer (Shoup) arithmetic on every limb
                                  {"MKCKKS_NO_FP64": "1", "MKCKKS_QSUM": "0"},
                                  {"MKCKKS_GENERIC_NTT": "1"}])    # LDS-stage kernels for both passes, nothing fused

@@ -252,6 +252,10 @@ int mkckks_reduce_scatter_sum_mod(mkckks_ctx *c, void *comm, const uint64_t *d_p
                                   uint32_t n_ct_shard, uint32_t nl, uint32_t n_ranks);
 const char *mkckks_comm_library(void);
 
+/* ---- diagnostics: in-kernel phase stamps of a -DMK_STAMP=1 build created under MKCKKS_STAMPS=1 (tools/stamps.py);
+ * h_out: 2^20 words; *n_out = words written, 0 in a product build */
+int mkckks_debug_stamps(mkckks_ctx *c, unsigned long long *h_out, uint32_t region, size_t *n_out);
+
 /* ---- introspection for tests: copy a CRT table to the host ---------------- */
 int mkckks_ctx_twiddles(const mkckks_ctx *c, uint32_t limb, int inverse, uint64_t *h_out /*N*/);
 

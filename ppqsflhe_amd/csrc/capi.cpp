@@ -211,6 +211,12 @@ int mkckks_fence_compute(mkckks_ctx *c) {
         c->eng->fence_compute();
     });
 }
+int mkckks_debug_stamps(mkckks_ctx *c, unsigned long long *h_out, uint32_t region, size_t *n_out) {
+    return guarded([&] {
+        need(c && h_out && n_out, "null argument");
+        *n_out = c->eng->debug_stamps(h_out, region);
+    });
+}
 int mkckks_count_noncanonical(mkckks_ctx *c, const uint64_t *d_ct, uint32_t n_ct, uint32_t nl, uint64_t *h_count) {
     return guarded([&] {
         need(c && h_count && (n_ct == 0 || d_ct), "null argument");

@@ -492,6 +492,11 @@ Knobs Knobs::from_env() {
         const int v = std::atoi(e);
         if (v >= 0 && v <= 2) k.qsum_pipe = v;
     }
+    k.cu_affine = env_flag("MKCKKS_CU_AFFINE", k.cu_affine);
+    if (const char *e = std::getenv("MKCKKS_CONV_PAIR2")) {
+        const int v = std::atoi(e);
+        if (v >= 0 && v <= 3) k.conv_pair2 = (uint32_t)v;
+    }
     k.generic_ntt = env_flag("MKCKKS_GENERIC_NTT", k.generic_ntt);
     k.no_pm = env_flag("MKCKKS_NO_PM", k.no_pm);
     k.no_fp64 = env_flag("MKCKKS_NO_FP64", k.no_fp64);
@@ -545,6 +550,14 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device), knobs
     }
     tabs_.h_fp_of = fp_of_.data();
     tabs_.stagger = knobs_.stagger;
+    tabs_.cu_affine = knobs_.cu_affine ? 1u : 0u;
+    tabs_.conv_pair2 = knobs_.conv_pair2;
+    tabs_.stamps = nullptr;
+    if (MK_STAMP && env_flag("MKCKKS_STAMPS", false)) {  // diagnostic build: phase stamps of the hot kernels (tools/stamps.py)
+        MK_HIP(hipMalloc(&d_stamps_, (size_t)STAMP_REGIONS * STAMP_REGION * sizeof(unsigned long long)));
+        MK_HIP(hipMemset(d_stamps_, 0, (size_t)STAMP_REGIONS * STAMP_REGION * sizeof(unsigned long long)));
+        tabs_.stamps = d_stamps_;
+    }
     MK_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));  // second client lane of reencrypt_sum
     MK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     MK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
@@ -621,7 +634,7 @@ Engine::~Engine() {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     for (void *p : {(void *)d_limb_, (void *)d_tw_, (void *)d_tw_sh_, (void *)d_itw_, (void *)d_itw_sh_, (void *)ws_,
-                    (void *)d_twb_, (void *)d_itwb_,
+                    (void *)d_twb_, (void *)d_itwb_, (void *)d_stamps_,
                     (void *)d_rot_, (void *)d_ksi_})
         if (p) (void)hipFree(p);
     for (void *p : owned_) (void)hipFree(p);
@@ -752,6 +765,16 @@ uint64_t Engine::count_noncanonical(const u64 *ct, uint32_t n_ct, uint32_t nl) {
     MK_HIP(hipMemcpyAsync(&h, d_bad, 8, hipMemcpyDeviceToHost, stream_));
     MK_HIP(hipStreamSynchronize(stream_));
     return h;
+}
+
+size_t Engine::debug_stamps(unsigned long long *h_out, uint32_t region) {
+    need_device();
+    if (!d_stamps_ || region >= STAMP_REGIONS) return 0;
+    MK_HIP(hipDeviceSynchronize());
+    MK_HIP(hipMemcpy(h_out, d_stamps_ + (size_t)region * STAMP_REGION, (size_t)STAMP_REGION * sizeof(unsigned long long),
+                     hipMemcpyDeviceToHost));
+    MK_HIP(hipMemset(d_stamps_ + (size_t)region * STAMP_REGION, 0, (size_t)STAMP_REGION * sizeof(unsigned long long)));
+    return STAMP_REGION;
 }
 
 void Engine::check_nl(uint32_t nl) const {
@@ -1039,6 +1062,24 @@ static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inve
 template <int LOG_H, int N_IN, int SRCMODE>
 static void launch_conv_col_n(const ConvIo &io, const ConvIo &iof, const dim3 &grid, const dim3 &gridf, const NttTables &T,
                               const DevConv &cv, const Lanes &ln) {
+    if constexpr (N_IN <= 4 && LOG_H >= 3) {
+        if (T.conv_pair2) {  // two targets of a class per workgroup: half the source traffic through each CU's L1
+            const uint32_t per = grid.x / (io.nsel ? io.nsel : 1), perf = gridf.x / (iof.nsel ? iof.nsel : 1);
+            if (io.nsel && (T.conv_pair2 & 1)) with_int_arith(T, [&](auto ar) {
+                k_conv_col2<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE>
+                    <<<dim3(per * ((io.nsel + 1) / 2)), NTT_THREADS, 0, ln.main>>>(io, T, cv);
+            });
+            else if (io.nsel) with_int_arith(T, [&](auto ar) {
+                k_conv_col<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE>
+                    <<<grid, NTT_THREADS, 0, ln.main>>>(io, T, cv);
+            });
+            if (iof.nsel && (T.conv_pair2 & 2))
+                k_conv_col2<LOG_H, N_IN, AR_FP, DevConv, SRCMODE><<<dim3(perf * ((iof.nsel + 1) / 2)), NTT_THREADS, 0, ln.main>>>(iof, T, cv);
+            else if (iof.nsel)
+                k_conv_col<LOG_H, N_IN, AR_FP, DevConv, SRCMODE><<<gridf, NTT_THREADS, 0, ln.main>>>(iof, T, cv);
+            return;
+        }
+    }
     launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
         [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
             k_conv_col<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE>

@@ -58,6 +58,9 @@ struct Knobs {
                                  // the summed ModDown conversions per group: 8 is +2.7 % against 4, 2 is -6.6 %)
     uint32_t stagger = 0;        // MKCKKS_STAGGER: start-phase stagger of each pass's first generation of workgroups, percent of
                                  // the built-in steps (ntt_radix.hpp: stagger_start); 0 = all workgroups start together
+    uint32_t conv_pair2 = 0;     // MKCKKS_CONV_PAIR2: bit 0 / bit 1 = two integer-class / fp64-class targets per workgroup in the ModUp
+                                 // conversion (k_conv_col2)
+    bool cu_affine = true;       // MKCKKS_CU_AFFINE=0: plain XCD-aware placement; default: workgroups that share operand tiles on the same CU (group_member)
     int qsum_pipe = 0;           // MKCKKS_QSUM_PIPE: 1 / 2 = k_qsum3p_fp (operand loads software-pipelined) at 3 / 2 waves per SIMD
     int qsum_geom = 3;           // MKCKKS_QSUM_GEOM: 3 = three-round k_qsum3_fp (3 waves per SIMD), 2 = two-round k_qsum_fp
     bool generic_ntt = false;    // MKCKKS_GENERIC_NTT=1: LDS-stage kernels for both passes
@@ -144,6 +147,9 @@ public:
     void decode(const u64 *m, double *vals, uint32_t n, uint32_t nl, double scale);
 
     void host_twiddles(uint32_t limb, bool inverse, std::vector<u64> &out) const;
+    // diagnostic builds (-DMK_STAMP=1, MKCKKS_STAMPS=1): copy one region of in-kernel phase stamps (2^20 words) to the
+    // host and clear it; 0 words in a product build
+    size_t debug_stamps(unsigned long long *h_out, uint32_t region);
 
 private:
     void need_device() const;
@@ -179,6 +185,7 @@ private:
     NttTables tabs_{};
     LimbConst *d_limb_ = nullptr;
     u64 *d_tw_ = nullptr, *d_tw_sh_ = nullptr, *d_itw_ = nullptr, *d_itw_sh_ = nullptr;
+    unsigned long long *d_stamps_ = nullptr;
     u64 *d_twb_ = nullptr, *d_itwb_ = nullptr;  // packed round-B tables of the row kernels (NttTables::twb)
     std::vector<uint8_t> fp_of_;  // per limb id: 1 = fp64 kernel instance
     // copies: tickets count up from 1; ticket t's completion event is ring slot t % COPY_RING

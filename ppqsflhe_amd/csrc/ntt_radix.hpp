@@ -77,6 +77,60 @@ MK_D void st_stream2(ulong2 *p, ulong2 v) {
     }
 }
 
+// In-kernel phase stamps (diagnostic build -DMK_STAMP=1 only; the product build compiles every call away).  A wave stamps
+// the shader clock (s_memtime) at phase boundaries and leaves the phase lengths in NttTables::stamps, region `REGION` of
+// STAMP_REGION entries: wave w of workgroup b writes 8 words at ((b * 4 + w) % (STAMP_REGION / 8)) * 8.  tools/stamps.py
+// reads them back through mkckks_debug_stamps.
+#ifndef MK_STAMP
+#define MK_STAMP 0
+#endif
+constexpr unsigned STAMP_REGION = 1u << 20, STAMP_REGIONS = 4;
+struct Stamper {
+    unsigned long long t[8];
+    MK_D Stamper() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = 0;
+    }
+    template <int K>
+    MK_D void mark() {
+        if (MK_STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            t[K] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // t[K] += now - since (for phases inside loops); returns now
+    template <int K>
+    MK_D unsigned long long add(unsigned long long since) {
+        if (MK_STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+            t[K] += now - since;
+            return now;
+        }
+        return 0;
+    }
+    MK_D unsigned long long now() {
+        if (MK_STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long v = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+            return v;
+        }
+        return 0;
+    }
+    template <int REGION>
+    MK_D void flush(unsigned long long *buf, bool differences) {
+        if (MK_STAMP && buf && (threadIdx.x & 63) == 0) {
+            const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            unsigned long long *p = buf + (size_t)REGION * STAMP_REGION + ((b * 4 + threadIdx.x / 64) % (STAMP_REGION / 8)) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p[i] = differences ? (i + 1 < 8 && t[i + 1] ? t[i + 1] - t[i] : 0) : t[i];
+        }
+    }
+};
+
 // Start-phase stagger.  Every workgroup of a pass does the same amount of work, so the W workgroups that start together
 // on a CU stay in step for the whole launch: they wait for their loads at the same time (the SIMDs idle) and compete for
 // the VALU at the same time.  Delaying the FIRST generation's workgroups by 0 .. W-1 W-ths of a workgroup's lifetime puts
@@ -90,6 +144,47 @@ MK_D void stagger_start(uint32_t pct) {
     if (b >= 256u * W) return;
     const uint32_t n = ((b >> 8) % W) * (uint32_t)STEP * pct / 100u;
     for (uint32_t i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+}
+
+// 1-D grids over (group, member): the members of a group share operand tiles (the source tiles of a conversion, the
+// twiddle / eval-key tiles of a row tile).  Workgroup b runs on XCD b % 8 (round-robin dispatch), so with 8 | groups a
+// group's members are made consecutive in ONE XCD's queue: its tiles are fetched over the fabric once and then hit in
+// that L2.  CU-affine form (NttTables::cu_affine): positions qidx, qidx + 32, qidx + 64, ... of an XCD's queue land on
+// the same CU, W at a time, and later workgroups inherit the slots of the ones they replace (tools/probe_dispatch.hip:
+// first-generation co-residents are exactly 256 blocks apart) -- a group's members are laid out along that direction,
+// so the workgroups that share tiles also share a CU and W - 1 of W tile loads can hit in its L1 instead of L2.
+// Placement is a speed matter only: any mapping that is a bijection gives the same results.
+MK_D void group_member(uint32_t b, uint32_t groups, uint32_t members, uint32_t cu_affine, uint32_t &grp, uint32_t &mem) {
+    if (groups % 8 == 0) {
+        const uint32_t xcd = b % 8, qidx = b / 8;
+        if (cu_affine && groups % 256 == 0) {
+            const uint32_t per = 32 * members, blk = qidx / per, r = qidx % per;
+            grp = (blk * 32 + r % 32) * 8 + xcd;
+            mem = r / 32;
+        } else {
+            grp = (qidx / members) * 8 + xcd;
+            mem = qidx % members;
+        }
+    } else {
+        grp = b / members;
+        mem = b % members;
+    }
+}
+
+// (item, column tile) of source-tile group `grp` in the conversion kernels.  grp % 8 is the XCD; with 8 | items every XCD
+// takes the items congruent to it and walks their column tiles consecutively, so the ~18 source tiles an XCD works on at
+// any moment cover all 16 column phases (128-byte offsets inside a 2-KiB row) instead of one or two -- the plain
+// item-major split hands XCD x only the tiles x and x + 8 (+1 % on the step, +2.3 % together with the CU-affine
+// placement, same-box A/B).
+MK_D void conv_item_tile(uint32_t grp, uint32_t groups, uint32_t items, uint32_t tiles, uint32_t &item, uint32_t &tile) {
+    if (groups % 8 == 0 && items % 8 == 0) {
+        const uint32_t u = grp / 8;
+        tile = u % tiles;
+        item = (u / tiles) * 8 + grp % 8;
+    } else {
+        item = grp / tiles;
+        tile = grp % tiles;
+    }
 }
 
 // twiddles of one round: w[(1<<s) - 1 + g] = table[(base_eff << s) + g]
@@ -362,22 +457,26 @@ MK_D void stage_twiddles_wave(u64 *ldsw, u64 *ldswp, const u64 *tw, const u64 *t
 // in x[]: round A, LDS exchange, round B, store rows H j + k (lazy [0,8q): the row pass finishes).
 template <int LOG_H, int AR>
 MK_D void col_forward_finish(u64 (&x)[1 << LOG_H], u64 *lds, const u64 *tw, const u64 *tw_sh, const LimbConst &lc,
-                             int j, int c, u64 *dst_col, uint32_t r2) {
+                             int j, int c, u64 *dst_col, uint32_t r2, Stamper *st = nullptr) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H;
     u64 w[H - 1], wp[H - 1], w2[H - 1], wp2[H - 1];
     load_round_twiddles<LOG_H>(tw, tw_sh, 1u, w, wp);  // same for every column: scalar loads
     radix_forward_any<LOG_H, AR>(x, w, wp, lc);
+    if (MK_STAMP && st) st->template mark<2>();
     // second-round twiddles are requested BEFORE the exchange: their L2 latency runs under the barrier wait
     load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w2, wp2);
 #pragma unroll
     for (int k = 0; k < H; ++k) lds[TL::at(k, j, c)] = x[k];  // row j + H k
     __syncthreads();
+    if (MK_STAMP && st) st->template mark<3>();
 #pragma unroll
     for (int k = 0; k < H; ++k) x[k] = lds[TL::at(j, k, c)];  // row H j + k
     radix_forward_any<LOG_H, AR>(x, w2, wp2, lc);
+    if (MK_STAMP && st) st->template mark<4>();
 #pragma unroll
     for (int k = 0; k < H; ++k) st_pass(dst_col + (size_t)(H * j + k) * r2, x[k]);  // lazy u64, or doubles on an fp limb
+    if (MK_STAMP && st) st->template mark<5>();
 }
 
 // Column pass over R1 = H*H rows: one workgroup = S = 256/H adjacent columns.  Global accesses are
@@ -456,6 +555,26 @@ struct ConvIo {
     unsigned long long target_mask;  // targets (indices into cv.dst_*) of this instance's arithmetic class
     uint32_t nsel;                   // popcount(target_mask)
 };
+#ifndef MK_CONV_DEPTH
+#define MK_CONV_DEPTH 8  // source slices (outputs) the conversion's loads run ahead
+#endif
+// timing probes of the conversion's source loads (diagnostic builds; results are wrong, the instruction stream is the same):
+// MK_PROBE = 1: every load of a thread reads row j of its source (16 distinct lines per wave instead of 256: L1-resident);
+// MK_PROBE = 2: no loads at all (the sources are register garbage)
+#ifndef MK_PROBE
+#define MK_PROBE 0
+#endif
+#if MK_PROBE == 1
+#define MK_PROBE_SRC(src, limb_off, row_off) (src)[(limb_off) + (size_t)j * r2 + 0 * (row_off)]
+#elif MK_PROBE == 2
+#define MK_PROBE_SRC(src, limb_off, row_off) ((u64)threadIdx.x * 0x9E3779B97F4A7C15ull + (limb_off) + (row_off))
+#else
+#define MK_PROBE_SRC(src, limb_off, row_off) (src)[(limb_off) + (row_off)]
+#endif
+#ifndef MK_CONV2_DEPTH
+#define MK_CONV2_DEPTH 4  // the same ring in the two-target kernel k_conv_col2
+#endif
+
 // canonical integer below 2^52 held in a double -> its 30-bit halves (what split30 gives for the u64)
 MK_D void split30_d(u64 dbl_bits, uint32_t &lo, uint32_t &hi) {
     const u64 b = dbits(bitsd(dbl_bits) + 4503599627370496.0) & 0xFFFFFFFFFFFFFull;  // mantissa of 2^52 + v is v
@@ -468,6 +587,68 @@ template <int SRCMODE>
 MK_D constexpr bool src_is_double(int i) {
     return SRCMODE == 1 || (SRCMODE == 2 && i > 0);
 }
+// per-target constants of a conversion with at most 4 sources (scalar registers: the target is workgroup-uniform)
+template <int N_IN>
+struct ConvConst {
+    uint32_t h0[N_IN], h1[N_IN];  // [S/s_i]_t as 30-bit halves (integer path)
+    double hd[N_IN], hq[N_IN];    // [S/s_i]_t and its quotient by t as doubles (fp64 path)
+};
+template <int N_IN, int AR, int SRCMODE, typename CONV>
+MK_D void conv_consts(const CONV &cv, uint32_t jt, ConvConst<N_IN> &k) {
+#pragma unroll
+    for (int i = 0; i < N_IN; ++i) {
+        if ((AR == AR_FP) && src_is_double<SRCMODE>(i)) {
+            k.hd[i] = cv.hat_d[i * cv.n_out + jt];
+            k.hq[i] = cv.hatq_d[i * cv.n_out + jt];
+        } else {
+            split30(cv.hat[i * cv.n_out + jt], k.h0[i], k.h1[i]);
+        }
+    }
+}
+// 30-bit halves of the sources that enter the integer column accumulation (packed sources as they are, double sources
+// split back); shared by every target computed from the same sources
+template <int N_IN, int SRCMODE>
+MK_D void conv_split_sources(const u64 (&p)[N_IN], uint32_t (&a0)[N_IN], uint32_t (&a1)[N_IN]) {
+#pragma unroll
+    for (int i = 0; i < N_IN; ++i) {
+        if (src_is_double<SRCMODE>(i)) {
+            split30_d(p[i], a0[i], a1[i]);
+        } else {
+            a0[i] = (uint32_t)p[i];
+            a1[i] = (uint32_t)(p[i] >> 32);
+        }
+    }
+}
+// one output  sum_i x_i [S/s_i]_t  in the range the first butterfly round of the target's arithmetic accepts.
+// Packed sources and [S/s_i]_t are below 2^60: 30-bit column accumulation, pure v_mad_u64_u32 chains.  Sources that
+// arrive as doubles (fp64-class limbs, below 1.25 * 2^50): an fp64-class target takes their products mod t on the FMA unit
+// (6 operations instead of 4 mads + a share of the Barrett step); an integer-class target uses the split halves.
+template <int N_IN, int AR, int SRCMODE>
+MK_D u64 conv_output(const u64 (&p)[N_IN], const uint32_t (&a0)[N_IN], const uint32_t (&a1)[N_IN], const ConvConst<N_IN> &k,
+                     const LimbConst &lc) {
+    if ((AR == AR_FP) && SRCMODE != 0) {
+        double acc = 0.0;
+        if (SRCMODE == 2) {  // the packed source(s): column accumulation, below 4q < 2^53
+            Cols ia{0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < N_IN; ++i)
+                if (!src_is_double<SRCMODE>(i)) mac_cols(ia, (uint32_t)p[i], (uint32_t)(p[i] >> 32), k.h0[i], k.h1[i]);
+            acc = (double)reduce_cols_lazy(ia, lc);
+        }
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i)
+            if (src_is_double<SRCMODE>(i)) acc += fp_mulmod(bitsd(p[i]), k.hd[i], k.hq[i], lc.qd);
+        // |acc| <= 4q + 4 * 0.8q < 2^53: exact; into the rounds' range
+        return dbits(fp_reduce(acc, lc.qd, lc.qinv));
+    }
+    Cols acc{0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < N_IN; ++i) mac_cols(acc, a0[i], a1[i], k.h0[i], k.h1[i]);
+    // < 4q (< 2.1U on a pseudo-Mersenne limb): the first butterfly stage accepts < 8q
+    const u64 v = AR == AR_PM ? pm_reduce_cols(acc, pm_consts(lc)) : reduce_cols_lazy(acc, lc);
+    return AR == AR_FP ? dbits(fp_reduce((double)v, lc.qd, lc.qinv)) : v;  // < 4q < 2^53: exact in a double
+}
+
 template <int LOG_H, int N_IN, int AR, typename CONV, int SRCMODE = 0>
 __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTables T, CONV cv) {
     using TL = ColTile<LOG_H>;
@@ -478,16 +659,10 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTable
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
     const uint32_t groups = io.items * tiles;  // source tiles
     uint32_t grp, jt;
-    if (groups % 8 == 0) {  // XCD-aware: blocks b and b+8 share an XCD (round-robin dispatch)
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / io.nsel) * 8 + xcd;
-        jt = qidx % io.nsel;
-    } else {
-        grp = blockIdx.x / io.nsel;
-        jt = blockIdx.x % io.nsel;
-    }
+    group_member(blockIdx.x, groups, io.nsel, T.cu_affine, grp, jt);
     jt = nth_set_bit(io.target_mask, jt);
-    const uint32_t item = grp / tiles, tile = grp % tiles;
+    uint32_t item, tile;
+    conv_item_tile(grp, groups, io.items, tiles, item, tile);
     const uint32_t id = cv.dst_id[jt];
     const LimbConst lc = T.limb[id];
     if ((lc.fp != 0) != (AR == AR_FP)) return;  // block-uniform
@@ -495,58 +670,35 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTable
     const u64 *src = io.in + (size_t)item * io.in_stride + tile * S + c;
     u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jt] * n + tile * S + c;
     u64 x[H];
-    if (N_IN <= 4) {
-        // packed sources and [S/s_i]_t are below 2^60: 30-bit column accumulation, pure v_mad_u64_u32 chains.
-        // Sources that arrive as doubles (fp64-class limbs, below 1.25 * 2^50): an fp64-class target takes their
-        // products x_i * [S/s_i]_t mod t on the FMA unit (6 operations instead of 4 mads + a share of the Barrett
-        // step); an integer-class target splits them back into 30-bit halves.
-        uint32_t h0[N_IN], h1[N_IN];
-        double hd[N_IN], hq[N_IN];
+    Stamper stm;
+    stm.mark<0>();
+    if constexpr (N_IN <= 4) {
+        ConvConst<N_IN> kc;
+        conv_consts<N_IN, AR, SRCMODE>(cv, jt, kc);
+        // Source loads run MK_CONV_DEPTH outputs ahead of their use.  Left to itself the compiler keeps about 8 loads in
+        // flight per wave (s_waitcnt vmcnt(7) before every product); a ring of DEPTH source slices held in registers makes
+        // it DEPTH * N_IN loads (+1 % on the step: the conversion phase -- three quarters of a wave's lifetime by the
+        // in-kernel stamps, profiles/r03_stamps_conv_qsum.txt -- is bound by what the CU's L1 can pull from L2, not by the
+        // number of loads in flight)
+        constexpr int DEPTH = MK_CONV_DEPTH < H ? MK_CONV_DEPTH : H;
+        u64 ring[DEPTH][N_IN];
 #pragma unroll
-        for (int i = 0; i < N_IN; ++i) {
-            if ((AR == AR_FP) && src_is_double<SRCMODE>(i)) {
-                hd[i] = cv.hat_d[i * cv.n_out + jt];
-                hq[i] = cv.hatq_d[i * cv.n_out + jt];
-            } else {
-                split30(cv.hat[i * cv.n_out + jt], h0[i], h1[i]);
-            }
-        }
+        for (int k = 0; k < DEPTH; ++k)
+#pragma unroll
+            for (int i = 0; i < N_IN; ++i) ring[k][i] = MK_PROBE_SRC(src, (size_t)cv.src_slot[i] * n, (size_t)(j + H * k) * r2);
 #pragma unroll
         for (int k = 0; k < H; ++k) {
             u64 p[N_IN];
 #pragma unroll
-            for (int i = 0; i < N_IN; ++i) p[i] = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2];
-            if ((AR == AR_FP) && SRCMODE != 0) {
-                double acc = 0.0;
-                if (SRCMODE == 2) {  // the packed source(s): column accumulation, below 4q < 2^53
-                    Cols ia{0, 0, 0};
-#pragma unroll
-                    for (int i = 0; i < N_IN; ++i)
-                        if (!src_is_double<SRCMODE>(i)) mac_cols(ia, (uint32_t)p[i], (uint32_t)(p[i] >> 32), h0[i], h1[i]);
-                    acc = (double)reduce_cols_lazy(ia, lc);
-                }
+            for (int i = 0; i < N_IN; ++i) p[i] = ring[k % DEPTH][i];
+            if (k + DEPTH < H) {  // refill the slice just taken
 #pragma unroll
                 for (int i = 0; i < N_IN; ++i)
-                    if (src_is_double<SRCMODE>(i)) acc += fp_mulmod(bitsd(p[i]), hd[i], hq[i], lc.qd);
-                // |acc| <= 4q + 4 * 0.8q < 2^53: exact; into the rounds' range
-                x[k] = dbits(fp_reduce(acc, lc.qd, lc.qinv));
-            } else {
-                Cols acc{0, 0, 0};
-#pragma unroll
-                for (int i = 0; i < N_IN; ++i) {
-                    uint32_t a0, a1;
-                    if (src_is_double<SRCMODE>(i)) {
-                        split30_d(p[i], a0, a1);
-                    } else {
-                        a0 = (uint32_t)p[i];
-                        a1 = (uint32_t)(p[i] >> 32);
-                    }
-                    mac_cols(acc, a0, a1, h0[i], h1[i]);
-                }
-                // < 4q (< 2.1U on a pseudo-Mersenne limb): the first butterfly stage accepts < 8q
-                x[k] = AR == AR_PM ? pm_reduce_cols(acc, pm_consts(lc)) : reduce_cols_lazy(acc, lc);
-                if (AR == AR_FP) x[k] = dbits(fp_reduce((double)x[k], lc.qd, lc.qinv));  // < 4q < 2^53: exact in a double
+                    ring[k % DEPTH][i] = MK_PROBE_SRC(src, (size_t)cv.src_slot[i] * n, (size_t)(j + H * (k + DEPTH)) * r2);
             }
+            uint32_t a0[N_IN], a1[N_IN];
+            if (!((AR == AR_FP) && SRCMODE != 0)) conv_split_sources<N_IN, SRCMODE>(p, a0, a1);
+            x[k] = conv_output<N_IN, AR, SRCMODE>(p, a0, a1, kc, lc);
         }
     } else {
         // 5..8 sources (e.g. alpha = K = 7 at L = 20): same 30-bit columns with the middle one split in two
@@ -565,7 +717,71 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTable
             if (AR == AR_FP) x[k] = dbits(fp_reduce((double)x[k], lc.qd, lc.qinv));
         }
     }
-    col_forward_finish<LOG_H, AR>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
+    stm.mark<1>();
+    col_forward_finish<LOG_H, AR>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2, &stm);
+    if (AR == AR_FP) stm.flush<0>(T.stamps, true);
+    else stm.flush<1>(T.stamps, true);
+}
+
+// k_conv_col for TWO targets of one arithmetic class per workgroup (at most 4 sources).  Every target limb's workgroup
+// pulls the same 4 source tiles (128 KiB) through its CU's L1 to produce 32 KiB, and that pull -- not the arithmetic, not
+// the number of loads in flight -- is what the conversion phase waits for (in-kernel stamps: 24 000 of a wave's 32 000
+// cycles; 16 bytes per clock and CU).  Two conversions from one pass over the sources halve it; the second target's 16
+// words wait in registers while the first goes through its column pass (3 waves per SIMD instead of 4).  The last group
+// of an odd target count carries one live target.
+template <int LOG_H, int N_IN, int AR, typename CONV, int SRCMODE = 0>
+__global__ __launch_bounds__(NTT_THREADS, 3) void k_conv_col2(ConvIo io, NttTables T, CONV cv) {
+    using TL = ColTile<LOG_H>;
+    constexpr int H = TL::H, S = TL::S;
+    static_assert(N_IN <= 4, "target pairs: at most 4 sources");
+    __shared__ u64 lds[TL::WORDS];
+    const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
+    const uint32_t groups = io.items * tiles, ntg = (io.nsel + 1) / 2;
+    uint32_t grp, jg;
+    group_member(blockIdx.x, groups, ntg, T.cu_affine, grp, jg);
+    const bool two = jg * 2 + 1 < io.nsel;  // workgroup-uniform
+    const uint32_t jta = nth_set_bit(io.target_mask, jg * 2), jtb = two ? nth_set_bit(io.target_mask, jg * 2 + 1) : jta;
+    uint32_t item, tile;
+    conv_item_tile(grp, groups, io.items, tiles, item, tile);
+    const uint32_t ida = cv.dst_id[jta], idb = cv.dst_id[jtb];
+    const LimbConst la = T.limb[ida], lb = T.limb[idb];
+    if ((la.fp != 0) != (AR == AR_FP) || (lb.fp != 0) != (AR == AR_FP)) return;  // never: the host pairs targets of one class
+    const int c = threadIdx.x % S, j = threadIdx.x / S;
+    const u64 *src = io.in + (size_t)item * io.in_stride + tile * S + c;
+    ConvConst<N_IN> ka, kb;
+    conv_consts<N_IN, AR, SRCMODE>(cv, jta, ka);
+    conv_consts<N_IN, AR, SRCMODE>(cv, jtb, kb);
+    constexpr int DEPTH = MK_CONV2_DEPTH < H ? MK_CONV2_DEPTH : H;
+    u64 ring[DEPTH][N_IN], xa[H], xb[H];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k)
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i) ring[k][i] = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        u64 p[N_IN];
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i) p[i] = ring[k % DEPTH][i];
+        if (k + DEPTH < H) {
+#pragma unroll
+            for (int i = 0; i < N_IN; ++i)
+                ring[k % DEPTH][i] = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * (k + DEPTH)) * r2];
+        }
+        uint32_t a0[N_IN], a1[N_IN];
+        if (!((AR == AR_FP) && SRCMODE != 0)) conv_split_sources<N_IN, SRCMODE>(p, a0, a1);  // once for both targets
+        xa[k] = conv_output<N_IN, AR, SRCMODE>(p, a0, a1, ka, la);
+        xb[k] = conv_output<N_IN, AR, SRCMODE>(p, a0, a1, kb, lb);
+    }
+    u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jta] * n + tile * S + c;
+    col_forward_finish<LOG_H, AR>(xa, lds, T.tw + (size_t)ida * n, T.tw_sh + (size_t)ida * n, la, j, c, dst, r2);
+    if (!two) return;
+    __syncthreads();  // the first target's exchange is read out
+    dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jtb] * n + tile * S + c;
+    // the second pass's twiddle loads must not be hoisted above the first pass (60 more live registers): its table
+    // pointers are opaque until here
+    const u64 *twb = T.tw + (size_t)idb * n, *twb_sh = T.tw_sh + (size_t)idb * n;
+    asm volatile("" : "+s"(twb), "+s"(twb_sh));
+    col_forward_finish<LOG_H, AR>(xb, lds, twb, twb_sh, lb, j, c, dst, r2);
 }
 
 // ---- ApproxModDown's conversion P -> Q_l for a whole group of clients at once ------------------------------------------
@@ -650,16 +866,25 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_psum(ConvIo io, Ntt
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
     const uint32_t groups = io.items * tiles;
     uint32_t grp, jt;
-    if (groups % 8 == 0) {
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / io.nsel) * 8 + xcd;
-        jt = qidx % io.nsel;
-    } else {
-        grp = blockIdx.x / io.nsel;
-        jt = blockIdx.x % io.nsel;
-    }
+    group_member(blockIdx.x, groups, io.nsel, T.cu_affine, grp, jt);
     jt = nth_set_bit(io.target_mask, jt);
-    const uint32_t item = grp / tiles, tile = grp % tiles;
+#if MK_TILE_MAJOR == 1  // experiment: XCD = item % 8 instead of tile % 8 (every XCD sees every column tile, i.e. every 128-byte phase of a row)
+    const uint32_t tile = grp / io.items, item = grp % io.items;
+#elif MK_TILE_MAJOR == 2  // experiment: XCD = item % 8 AND the tiles of an item consecutive in its queue: the ~18 source tiles an XCD
+    // works on at any moment cover all 16 column phases (128-byte offsets inside a 2-KiB row) instead of one or two
+    uint32_t item, tile;
+    if (groups % 8 == 0 && io.items % 8 == 0) {
+        const uint32_t u = grp / 8;
+        tile = u % tiles;
+        item = (u / tiles) * 8 + grp % 8;
+    } else {
+        item = grp / tiles;
+        tile = grp % tiles;
+    }
+#else
+    uint32_t item, tile;
+    conv_item_tile(grp, groups, io.items, tiles, item, tile);
+#endif
     const uint32_t id = cv.dst_id[jt];
     const LimbConst lc = T.limb[id];
     if ((lc.fp != 0) != (AR == AR_FP)) return;  // never: the host selects the targets of this instance's class
@@ -763,6 +988,64 @@ struct TailArgs {
     uint32_t accumulate; // out += result (running aggregate over clients) instead of out = result
 };
 
+// ---- wavefront-shuffle exchange (experiment, -DMK_ROW_SHUFFLE=1) ---------------------------------------------------
+// The hand-off between the two rounds of a 256-point row is a 16 x 16 transpose between the lane index j (16 lanes own a
+// row) and the register index k.  Instead of the wave-private LDS tile it can be done in registers with four butterfly
+// steps over the lane bits 8, 4, 2, 1: in step b the element (lane j, register k) with bit b of j != bit b of k trades
+// places with (j ^ b, k ^ b).  Lane distances 8 and 4 are DPP row shifts whose bank mask (groups of 4 lanes) picks the
+// receiving half directly: 2 v_mov_b32_dpp per 64-bit word.  Distances 2 and 1 stay inside a quad (quad_perm), where the
+// bank mask cannot tell the lanes apart: select what to send, move, select where it lands -- 4 instructions per 32 bits.
+// 192 VALU instructions per thread replace 16 ds_write_b64 + 8 ds_read2_b64 (measurement: DESIGN.md section 4).
+#ifndef MK_ROW_SHUFFLE
+#define MK_ROW_SHUFFLE 0
+#endif
+template <int CTRL, int BANKS>
+MK_D u64 dpp_word(u64 keep, u64 from) {  // lanes of the banks in BANKS: `from` read at the lane CTRL points to; others: keep
+    const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)keep, (int)(uint32_t)from, CTRL, 0xf, BANKS, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(keep >> 32), (int)(uint32_t)(from >> 32), CTRL, 0xf, BANKS, false);
+    return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+template <int CTRL>
+MK_D u64 dpp_quad(u64 v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+// x[k] of lane j (j = lane % 16)  <->  x[j] of lane k, inside every group of 16 lanes
+MK_D void transpose16_shuffle(u64 (&x)[16], int j) {
+    constexpr int ROW_SHL = 0x100, ROW_SHR = 0x110;  // DPP controls row_shl:n = 0x100 + n, row_shr:n = 0x110 + n
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) {  // lane bit 8: lanes 0-7 (banks 0, 1) take register k0 of lane + 8 into k0 + 8, lanes 8-15 the reverse
+        const u64 a = x[k0], b = x[k0 + 8];
+        x[k0 + 8] = dpp_word<ROW_SHL + 8, 0x3>(b, a);
+        x[k0] = dpp_word<ROW_SHR + 8, 0xc>(a, b);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // lane bit 4: banks 0, 2 against banks 1, 3
+        const int k0 = (i & 3) | ((i & 4) << 1);
+        const u64 a = x[k0], b = x[k0 + 4];
+        x[k0 + 4] = dpp_word<ROW_SHL + 4, 0x5>(b, a);
+        x[k0] = dpp_word<ROW_SHR + 4, 0xa>(a, b);
+    }
+    const bool b2 = (j & 2) != 0, b1 = (j & 1) != 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // lane bit 2: partner = lane ^ 2, quad_perm [2, 3, 0, 1]
+        const int k0 = (i & 1) | ((i & 6) << 1);
+        const u64 a = x[k0], b = x[k0 + 2];
+        const u64 got = dpp_quad<0x4E>(b2 ? a : b);
+        x[k0] = b2 ? got : a;
+        x[k0 + 2] = b2 ? b : got;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // lane bit 1: partner = lane ^ 1, quad_perm [1, 0, 3, 2]
+        const int k0 = i << 1;
+        const u64 a = x[k0], b = x[k0 + 1];
+        const u64 got = dpp_quad<0xB1>(b1 ? a : b);
+        x[k0] = b1 ? got : a;
+        x[k0 + 1] = b1 ? b : got;
+    }
+}
+
 // Row pass over rows of R2 = H*H contiguous words: one workgroup = S consecutive rows (S*R2 contiguous
 // words).  The side that needs per-thread contiguous runs goes through LDS with coalesced 16-B accesses.
 template <int LOG_H, bool INV, int AR>
@@ -779,14 +1062,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t tiles = r1 / S, groups = tiles * io.nsel, n_polys = gridDim.x / groups;
     uint32_t grp, poly;
-    if (groups % 8 == 0) {
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / n_polys) * 8 + xcd;
-        poly = qidx % n_polys;
-    } else {
-        grp = blockIdx.x / n_polys;
-        poly = blockIdx.x % n_polys;
-    }
+    group_member(blockIdx.x, groups, n_polys, T.cu_affine, grp, poly);
     const uint32_t sl = nth_set_bit(io.slot_mask, grp / tiles);
     if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;  // block-uniform
     const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
@@ -809,11 +1085,15 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         radix_forward_any<LOG_H, AR>(x, w, wp, lc);
         u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
         load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
+        if constexpr (MK_ROW_SHUFFLE && LOG_H == 4) {
+            transpose16_shuffle(x, j);
+        } else {
 #pragma unroll
-        for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
-        wave_lds_sync();
+            for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
+            wave_lds_sync();
 #pragma unroll
-        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
+            for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
+        }
         radix_forward_any<LOG_H, AR>(x, w2, wp2, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k)  // canonical u64, own words only
@@ -872,11 +1152,15 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
             for (int k = 0; k < H; ++k) x[k] = dbits((double)x[k]);
         }
         radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
+        if constexpr (MK_ROW_SHUFFLE && LOG_H == 4) {
+            transpose16_shuffle(x, j);
+        } else {
 #pragma unroll
-        for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = x[k];
-        wave_lds_sync();
+            for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = x[k];
+            wave_lds_sync();
 #pragma unroll
-        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, j + H * k)];
+            for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, j + H * k)];
+        }
         TA::fetch(twa, twa_sh, g, w, wp);
         radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
 #pragma unroll
@@ -913,14 +1197,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, 
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
     uint32_t grp, poly;
-    if (groups % 8 == 0) {
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / a.n_polys) * 8 + xcd;
-        poly = qidx % a.n_polys;
-    } else {
-        grp = blockIdx.x / a.n_polys;
-        poly = blockIdx.x % a.n_polys;
-    }
+    group_member(blockIdx.x, groups, a.n_polys, T.cu_affine, grp, poly);
     const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);  // Q limb: slot == limb id
     const LimbConst lc = T.limb[sl];
     if ((lc.fp != 0) != (AR == AR_FP)) return;
@@ -1002,14 +1279,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, Ntt
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
     uint32_t grp, poly;
-    if (groups % 8 == 0) {
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / a.n_polys) * 8 + xcd;
-        poly = qidx % a.n_polys;
-    } else {
-        grp = blockIdx.x / a.n_polys;
-        poly = blockIdx.x % a.n_polys;
-    }
+    group_member(blockIdx.x, groups, a.n_polys, T.cu_affine, grp, poly);
     const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);  // Q limb: slot == limb id
     const LimbConst lc = T.limb[sl];
     if ((lc.fp != 0) != (AR == AR_FP)) return;
@@ -1149,14 +1419,7 @@ __global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_inner_fp(InnerArgs a
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
     uint32_t grp, item;
-    if (groups % 8 == 0) {  // the items of one (limb, tile) share its eval-key and twiddle tiles: same XCD, consecutive
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / a.items) * 8 + xcd;
-        item = qidx % a.items;
-    } else {
-        grp = blockIdx.x / a.items;
-        item = blockIdx.x % a.items;
-    }
+    group_member(blockIdx.x, groups, a.items, T.cu_affine, grp, item);
     const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);  // Q limb: slot == limb id
     const LimbConst lc = T.limb[sl];
     const int own = (int)(sl / a.alpha);
@@ -1277,14 +1540,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T,
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t tiles = r1 / S, groups = tiles * io.nsel, n_polys = gridDim.x / groups;
     uint32_t grp, poly;
-    if (groups % 8 == 0) {
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / n_polys) * 8 + xcd;
-        poly = qidx % n_polys;
-    } else {
-        grp = blockIdx.x / n_polys;
-        poly = blockIdx.x % n_polys;
-    }
+    group_member(blockIdx.x, groups, n_polys, T.cu_affine, grp, poly);
     const uint32_t sl = nth_set_bit(io.slot_mask, grp / tiles);
     if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;
     const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
@@ -1566,14 +1822,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_sum(SumArgs a, Ntt
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
     uint32_t grp, poly;
-    if (groups % 8 == 0) {
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / a.n_polys) * 8 + xcd;
-        poly = qidx % a.n_polys;
-    } else {
-        grp = blockIdx.x / a.n_polys;
-        poly = blockIdx.x % a.n_polys;
-    }
+    group_member(blockIdx.x, groups, a.n_polys, T.cu_affine, grp, poly);
     const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);
     const LimbConst lc = T.limb[sl];
     if ((lc.fp != 0) != (AR == AR_FP)) return;
@@ -1649,14 +1898,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, N
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
     uint32_t grp, item;
-    if (groups % 8 == 0) {
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / a.items) * 8 + xcd;
-        item = qidx % a.items;
-    } else {
-        grp = blockIdx.x / a.items;
-        item = blockIdx.x % a.items;
-    }
+    group_member(blockIdx.x, groups, a.items, T.cu_affine, grp, item);
     const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);
     const LimbConst lc = T.limb[sl];
     const int own = (int)(sl / a.alpha);
@@ -1771,14 +2013,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_once(TailOnceArgs 
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
     uint32_t grp, poly;
-    if (groups % 8 == 0) {
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / a.n_polys) * 8 + xcd;
-        poly = qidx % a.n_polys;
-    } else {
-        grp = blockIdx.x / a.n_polys;
-        poly = blockIdx.x % a.n_polys;
-    }
+    group_member(blockIdx.x, groups, a.n_polys, T.cu_affine, grp, poly);
     const uint32_t rank = grp / tiles, sl = nth_set_bit(a.slot_mask, rank);  // Q limb: slot == limb id
     const LimbConst lc = T.limb[sl];
     const uint32_t row0 = (grp % tiles) * S;
@@ -1922,14 +2157,7 @@ __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
     uint32_t grp, item;
-    if (groups % 8 == 0) {
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / a.items) * 8 + xcd;
-        item = qidx % a.items;
-    } else {
-        grp = blockIdx.x / a.items;
-        item = blockIdx.x % a.items;
-    }
+    group_member(blockIdx.x, groups, a.items, T.cu_affine, grp, item);
     const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);
     const uint32_t id = limb_id_of(sl, a.nl, L);
     const LimbConst lc = T.limb[id];

@@ -48,14 +48,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_qsum_fp(QSumArgs a, NttTable
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
     uint32_t grp, b;
-    if (groups % 8 == 0) {  // the ciphertexts of one (limb, tile) share its eval-key and twiddle tiles: same XCD, consecutive
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / a.cnt) * 8 + xcd;
-        b = qidx % a.cnt;
-    } else {
-        grp = blockIdx.x / a.cnt;
-        b = blockIdx.x % a.cnt;
-    }
+    group_member(blockIdx.x, groups, a.cnt, T.cu_affine, grp, b);
     const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);  // Q limb: slot == limb id
     const LimbConst lc = T.limb[sl];
     const int own = (int)(sl / a.alpha);
@@ -237,14 +230,7 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
     uint32_t grp, b;
-    if (groups % 8 == 0) {
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / a.cnt) * 8 + xcd;
-        b = qidx % a.cnt;
-    } else {
-        grp = blockIdx.x / a.cnt;
-        b = blockIdx.x % a.cnt;
-    }
+    group_member(blockIdx.x, groups, a.cnt, T.cu_affine, grp, b);
     const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);
     const LimbConst lc = T.limb[sl];
     const int own = (int)(sl / a.alpha);
@@ -289,6 +275,7 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
         }
         return a.conv + (((size_t)b * 2 + u) * a.nl + sl) * n + th_off;
     };
+    Stamper stm;  // diagnostic build: [0] own-digit products, [1] transforms, [2] digit products, [3] conversions + store, [4] total
     auto transform = [&](u64 (&x)[8], const u64 *next) {
         wave_lds_sync();  // previous transform's consumers finished reading this wave's rows
         row3_forward<AR_FP, LOGC, MK_QSUM_PARK_C != 0>(x, c, wc, wpc, lc);
@@ -307,6 +294,8 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
         for (int k = 0; k < 8; ++k) x[k] = ld_stream(src + TPR * k);
     }
     __syncthreads();  // twiddles staged
+    const unsigned long long t_begin = stm.now();
+    unsigned long long t_mark = t_begin;
 #pragma unroll 1
     for (uint32_t cl = 0; cl < a.n_clients; ++cl) {
         const u64 *ct = a.cts + (size_t)cl * a.ct_cstride + (size_t)b * a.ct_stride + (size_t)sl * n + tile_off;
@@ -334,12 +323,14 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
                 }
             }
         }
+        t_mark = stm.add<0>(t_mark);
         int nd = ND;
         if (ND == 1) asm volatile("" : "+s"(nd));  // two digits: keep this a loop -- inlined into the client loop it costs 50 more spilled registers
 #pragma unroll 1
         for (int u = 0; u < nd; ++u) {
             const bool last_u = u == ND - 1;
             transform(x, last_u ? src_of(cl + 1, 0) : src_of(cl, u + 1));
+            t_mark = stm.add<1>(t_mark);
             const int dj = u < own ? u : u + 1;
             const u64 *e0 = ek + ((size_t)dj * 2 + 0) * a.D * n, *e1 = ek + ((size_t)dj * 2 + 1) * a.D * n;
 #pragma unroll
@@ -360,6 +351,7 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
                     acc1[i].y = fp_reduce(acc1[i].y, q, qinv);
                 }
             }
+            t_mark = stm.add<2>(t_mark);
         }
     }
 #pragma unroll 1
@@ -390,6 +382,9 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
         reinterpret_cast<ulong2 *>(o0)[e] = r0;
         reinterpret_cast<ulong2 *>(o1)[e] = r1v;
     }
+    t_mark = stm.add<3>(t_mark);
+    stm.add<4>(t_begin);
+    stm.flush<2>(T.stamps, false);
 }
 
 // k_qsum3_fp with the operand loads software-pipelined (round 3).  vmcnt retires loads IN ORDER, and k_qsum3_fp asked for
@@ -427,14 +422,7 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3p_fp(QSumArgs a, Ntt
     const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
     const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
     uint32_t grp, b;
-    if (groups % 8 == 0) {
-        const uint32_t xcd = blockIdx.x % 8, qidx = blockIdx.x / 8;
-        grp = (qidx / a.cnt) * 8 + xcd;
-        b = qidx % a.cnt;
-    } else {
-        grp = blockIdx.x / a.cnt;
-        b = blockIdx.x % a.cnt;
-    }
+    group_member(blockIdx.x, groups, a.cnt, T.cu_affine, grp, b);
     const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);
     const LimbConst lc = T.limb[sl];
     const int own = (int)(sl / a.alpha);

@@ -1,0 +1,11 @@
+#!/bin/bash
+set -o pipefail
+out=gpurun_out
+export TMPDIR=/tmp
+MKCKKS_LIB=$PWD/ppqsflhe_amd/libmkckks_wide.so timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "modup_moddown or reencrypt_sum or full_size" > $out/r03e_tests.log 2>&1; rc=$?
+tail -3 $out/r03e_tests.log
+[ $rc -ge 124 ] && exit 1
+bash tools/exp_ab.sh r03e base "X=0" "MKCKKS_LIB=$PWD/ppqsflhe_amd/libmkckks_wide.so"
+MKCKKS_LIB=$PWD/ppqsflhe_amd/libmkckks_wide.so timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/r03e_trace -o runc -- python3 bench.py --steps 5 --warmup 2 --no-cpu --min-seconds 0 > $out/r03e_trace_bench.json 2> $out/r03e_trace.err
+python tools/kstats.py $out/r03e_trace 7 > $out/r03e_kernel_stats.txt
+echo done

@@ -493,6 +493,7 @@ Knobs Knobs::from_env() {
         if (v >= 0 && v <= 2) k.qsum_pipe = v;
     }
     k.cu_affine = env_flag("MKCKKS_CU_AFFINE", k.cu_affine);
+    k.conv_lds = env_flag("MKCKKS_CONV_LDS", k.conv_lds);
     if (const char *e = std::getenv("MKCKKS_CONV_PAIR2")) {
         const int v = std::atoi(e);
         if (v >= 0 && v <= 3) k.conv_pair2 = (uint32_t)v;
@@ -552,6 +553,7 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device), knobs
     tabs_.stagger = knobs_.stagger;
     tabs_.cu_affine = knobs_.cu_affine ? 1u : 0u;
     tabs_.conv_pair2 = knobs_.conv_pair2;
+    tabs_.conv_lds = knobs_.conv_lds ? 1u : 0u;
     tabs_.stamps = nullptr;
     if (MK_STAMP && env_flag("MKCKKS_STAMPS", false)) {  // diagnostic build: phase stamps of the hot kernels (tools/stamps.py)
         MK_HIP(hipMalloc(&d_stamps_, (size_t)STAMP_REGIONS * STAMP_REGION * sizeof(unsigned long long)));
@@ -1180,8 +1182,36 @@ static void launch_icol_sum(const u64 *pc, u64 *psum, const NttTables &T, const 
     }
     MK_HIP(hipGetLastError());
 }
+// ModUp conversion with the source tile staged in LDS and every target of the digit done by one workgroup (k_conv_lds);
+// needs 256-point columns, at most 4 sources and both arithmetic classes wanted.  Task order: integer-class targets first.
+template <int N_IN>
+static void launch_conv_lds_n(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s, int srcmode) {
+    ConvTargets tg{};
+    for (int pass = 0; pass < 2; ++pass)
+        for (uint32_t j = 0; j < cv.n_out; ++j)
+            if ((T.h_fp_of[cv.dst_id[j]] != 0) == (pass == 1)) tg.idx[tg.n++] = (uint8_t)j;
+    const dim3 grid(io.items * ((1u << T.log_r2) / CL_COLS));
+    with_int_arith(T, [&](auto ar) {
+        constexpr int ARI = decltype(ar)::value;
+        if (srcmode == 1) k_conv_lds<N_IN, ARI, DevConv, 1><<<grid, NTT_THREADS, 0, s>>>(io, T, cv, tg);
+        else if (srcmode == 2) k_conv_lds<N_IN, ARI, DevConv, (N_IN > 1 ? 2 : 0)><<<grid, NTT_THREADS, 0, s>>>(io, T, cv, tg);
+        else k_conv_lds<N_IN, ARI, DevConv, 0><<<grid, NTT_THREADS, 0, s>>>(io, T, cv, tg);
+    });
+}
+static bool launch_conv_lds(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s, int srcmode) {
+    if (T.log_r1 != 8 || cv.n_in > 4 || cv.n_out > (uint32_t)MAX_CONV_TARGETS) return false;
+    switch (cv.n_in) {
+        case 1: launch_conv_lds_n<1>(io, T, cv, s, srcmode); break;
+        case 2: launch_conv_lds_n<2>(io, T, cv, s, srcmode); break;
+        case 3: launch_conv_lds_n<3>(io, T, cv, s, srcmode); break;
+        default: launch_conv_lds_n<4>(io, T, cv, s, srcmode); break;
+    }
+    MK_HIP(hipGetLastError());
+    return true;
+}
 static bool launch_conv_col(const ConvIo &io, const NttTables &T, const DevConv &cv, const Lanes &s, int srcmode = 0,
                             unsigned classes = 3) {
+    if (T.conv_lds && classes == 3 && launch_conv_lds(io, T, cv, s.main, srcmode)) return true;
     switch (fast_log_h(T.log_r1, 1u << T.log_r2)) {
         case 4: launch_conv_col_h<4>(io, T, cv, s, srcmode, classes); break;
         case 3: launch_conv_col_h<3>(io, T, cv, s, srcmode, classes); break;

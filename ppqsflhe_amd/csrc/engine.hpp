@@ -58,6 +58,7 @@ struct Knobs {
                                  // the summed ModDown conversions per group: 8 is +2.7 % against 4, 2 is -6.6 %)
     uint32_t stagger = 0;        // MKCKKS_STAGGER: start-phase stagger of each pass's first generation of workgroups, percent of
                                  // the built-in steps (ntt_radix.hpp: stagger_start); 0 = all workgroups start together
+    bool conv_lds = false;       // MKCKKS_CONV_LDS=1: ModUp conversion with the source tile in LDS, all targets per workgroup (k_conv_lds)
     uint32_t conv_pair2 = 0;     // MKCKKS_CONV_PAIR2: bit 0 / bit 1 = two integer-class / fp64-class targets per workgroup in the ModUp
                                  // conversion (k_conv_col2)
     bool cu_affine = true;       // MKCKKS_CU_AFFINE=0: plain XCD-aware placement; default: workgroups that share operand tiles on the same CU (group_member)

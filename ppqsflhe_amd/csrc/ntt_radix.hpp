@@ -354,6 +354,79 @@ MK_D void radix_inverse_any(u64 (&x)[1 << LOG_H], const u64 (&w)[(1 << LOG_H) - 
     else radix_inverse<LOG_H>(x, w, wp, lc.q, lc.q2);
 }
 
+// The same rounds with the twiddles of a stage fetched right before the stage instead of all 2 (H - 1) words up front:
+// `pair_at(i)` returns twiddle i of the round (w, companion) -- an LDS read in the column kernels (ColTwB), whose latency
+// is short enough to be taken stage by stage; the 60 registers of a whole round's twiddles shrink to the 32 of its last stage.
+template <int AR, bool EVEN>
+MK_D void butterfly_forward_any(u64 &x, u64 &y, u64 w, u64 wp, const LimbConst &lc, const PmK &P) {
+    if (AR == AR_FP) {
+        if (EVEN) ct_butterfly_fp(x, y, w, wp, lc.qd, lc.qinv);
+        else ct_butterfly_fp_nr(x, y, w, wp, lc.qd);
+    } else if (AR == AR_PM) {
+        if (EVEN) ct_butterfly_pm_f(x, y, w, wp, P);
+        else ct_butterfly_pm_n(x, y, w, wp, P);
+    } else {
+        if (EVEN) ct_butterfly_c4(x, y, w, wp, lc.q, lc.q2, lc.q2 + lc.q2);
+        else ct_butterfly_nc(x, y, w, wp, lc.q, lc.q2);
+    }
+}
+template <int AR>
+MK_D void butterfly_inverse_any(u64 &x, u64 &y, u64 w, u64 wp, const LimbConst &lc, const PmK &P) {
+    if (AR == AR_FP) gs_butterfly_fp(x, y, w, wp, lc.qd, lc.qinv);
+    else if (AR == AR_PM) gs_butterfly_pm(x, y, w, wp, P);
+    else gs_butterfly(x, y, w, wp, lc.q, lc.q2);
+}
+template <int LOG_H, int AR, int S_, typename F>
+MK_D void radix_forward_stage(u64 (&x)[1 << LOG_H], F &pair_at, const LimbConst &lc, const PmK &P) {
+    constexpr int H = 1 << LOG_H, dist = H >> (S_ + 1);
+    u64 w[1 << S_], wp[1 << S_];
+    __builtin_amdgcn_sched_barrier(0);  // this stage's twiddles are fetched here, not at the top of the round
+#pragma unroll
+    for (int g = 0; g < (1 << S_); ++g) {
+        const ulong2 t = pair_at((1 << S_) - 1 + g);
+        w[g] = t.x;
+        wp[g] = t.y;
+    }
+#pragma unroll
+    for (int p = 0; p < H / 2; ++p) {
+        const int g = p / dist, k0 = g * 2 * dist + (p % dist);
+        butterfly_forward_any<AR, S_ % 2 == 0>(x[k0], x[k0 + dist], w[g], wp[g], lc, P);
+    }
+}
+template <int LOG_H, int AR, int S_, typename F>
+MK_D void radix_inverse_stage(u64 (&x)[1 << LOG_H], F &pair_at, const LimbConst &lc, const PmK &P) {
+    constexpr int H = 1 << LOG_H, dist = H >> (S_ + 1);
+    u64 w[1 << S_], wp[1 << S_];
+    __builtin_amdgcn_sched_barrier(0);  // this stage's twiddles are fetched here, not at the top of the round
+#pragma unroll
+    for (int g = 0; g < (1 << S_); ++g) {
+        const ulong2 t = pair_at((1 << S_) - 1 + g);
+        w[g] = t.x;
+        wp[g] = t.y;
+    }
+#pragma unroll
+    for (int p = 0; p < H / 2; ++p) {
+        const int g = p / dist, k0 = g * 2 * dist + (p % dist);
+        butterfly_inverse_any<AR>(x[k0], x[k0 + dist], w[g], wp[g], lc, P);
+    }
+}
+template <int LOG_H, int AR, typename F>
+MK_D void radix_forward_staged(u64 (&x)[1 << LOG_H], F &&pair_at, const LimbConst &lc) {
+    const PmK P = AR == AR_PM ? pm_consts(lc) : PmK{};
+    radix_forward_stage<LOG_H, AR, 0>(x, pair_at, lc, P);
+    if constexpr (LOG_H > 1) radix_forward_stage<LOG_H, AR, 1>(x, pair_at, lc, P);
+    if constexpr (LOG_H > 2) radix_forward_stage<LOG_H, AR, 2>(x, pair_at, lc, P);
+    if constexpr (LOG_H > 3) radix_forward_stage<LOG_H, AR, 3>(x, pair_at, lc, P);
+}
+template <int LOG_H, int AR, typename F>
+MK_D void radix_inverse_staged(u64 (&x)[1 << LOG_H], F &&pair_at, const LimbConst &lc) {
+    const PmK P = AR == AR_PM ? pm_consts(lc) : PmK{};
+    if constexpr (LOG_H > 3) radix_inverse_stage<LOG_H, AR, 3>(x, pair_at, lc, P);
+    if constexpr (LOG_H > 2) radix_inverse_stage<LOG_H, AR, 2>(x, pair_at, lc, P);
+    if constexpr (LOG_H > 1) radix_inverse_stage<LOG_H, AR, 1>(x, pair_at, lc, P);
+    radix_inverse_stage<LOG_H, AR, 0>(x, pair_at, lc, P);
+}
+
 // ---- LDS layouts -------------------------------------------------------------------
 // column tile: R rows x S columns (S = 256/H), stored as H blocks of H rows; blocks are padded by
 // 16 words when S == 16 so that two neighbouring blocks land in different halves of a bank row.
@@ -370,6 +443,60 @@ struct RowTile {
     static constexpr int H = 1 << LOG_H, S = 256 / H, R = H * H, RS = R + H;
     static constexpr int WORDS = S * RS;
     static MK_D int at(int g, int x) { return g * RS + x + (x >> LOG_H); }
+};
+
+// Column-pass round-B twiddles through LDS (round 3).  In round B thread (j, c) needs the H - 1 pairs of base H + j -- the
+// same for the S columns c, so as per-thread global loads each wave instruction fetches 64 / S distinct words, and the 2 (H - 1)
+// loads per thread are a quarter to a half of everything the column kernels send through the CU's texture addresser, the
+// unit the PMC counters show saturated in them (TA busy 0.77-0.86, profiles/r03_mempipe_counters.txt).  A wave owns
+// JW = 64 / S values of j; their stage-s entries are ONE contiguous run of JW 2^s table words starting at (H + j0) << s,
+// so the wave loads its JW (H - 1) pairs once, coalesced, into a wave-private LDS strip (no workgroup barrier) and every
+// thread takes its pairs with broadcast LDS reads.
+template <int LOG_H>
+struct ColTwB {
+    static constexpr int H = 1 << LOG_H, S = 256 / H, JW = 64 / S, PAIRS = JW * (H - 1);  // round B, per wave
+    static constexpr int STRIP = PAIRS + (H - 1);  // + the H - 1 pairs of round A (base 1: the same for the whole limb)
+    static constexpr int WORDS = (NTT_THREADS / 64) * STRIP * 2;
+    static_assert(PAIRS <= 64 && H - 1 <= 64, "one pair per lane and round");
+    static MK_D void stage(u64 *strip, const u64 *tw, const u64 *tw_sh) {  // strip: this workgroup's WORDS words
+        const int lane = threadIdx.x % 64, wv = threadIdx.x / 64;
+        if (lane < PAIRS) {
+            const int s = 31 - __clz(lane / JW + 1), off = lane - JW * ((1 << s) - 1);
+            const uint32_t idx = ((uint32_t)(H + JW * wv) << s) + (uint32_t)off;
+            *reinterpret_cast<ulong2 *>(strip + (wv * STRIP + lane) * 2) = ulong2{tw[idx], tw_sh[idx]};
+        }
+        if (lane < H - 1)  // round A: table entries 1 .. H - 1 in order (entry (1 << s) + g is twiddle (1 << s) - 1 + g of the round)
+            *reinterpret_cast<ulong2 *>(strip + (wv * STRIP + PAIRS + lane) * 2) = ulong2{tw[1 + lane], tw_sh[1 + lane]};
+    }
+    static MK_D void fetch(const u64 *strip, int j, u64 (&w)[H - 1], u64 (&wp)[H - 1]) {
+        const int wv = threadIdx.x / 64, jj = j - JW * wv;
+#pragma unroll
+        for (int s = 0; s < LOG_H; ++s)
+#pragma unroll
+            for (int g = 0; g < (1 << s); ++g) {
+                const ulong2 t = *reinterpret_cast<const ulong2 *>(strip + (wv * STRIP + JW * ((1 << s) - 1) + (jj << s) + g) * 2);
+                w[(1 << s) - 1 + g] = t.x;
+                wp[(1 << s) - 1 + g] = t.y;
+            }
+    }
+    // twiddle i of round B / round A of this thread, for radix_*_staged
+    static MK_D ulong2 pair_b(const u64 *strip, int j, int i) {
+        const int wv = threadIdx.x / 64, jj = j - JW * wv;
+        const int s = 31 - __clz(i + 1), g = i - ((1 << s) - 1);  // constants after unrolling
+        return *reinterpret_cast<const ulong2 *>(strip + (wv * STRIP + JW * ((1 << s) - 1) + (jj << s) + g) * 2);
+    }
+    static MK_D ulong2 pair_a(const u64 *strip, int i) {
+        return *reinterpret_cast<const ulong2 *>(strip + ((threadIdx.x / 64) * STRIP + PAIRS + i) * 2);
+    }
+    static MK_D void fetch_a(const u64 *strip, u64 (&w)[H - 1], u64 (&wp)[H - 1]) {
+        const int wv = threadIdx.x / 64;
+#pragma unroll
+        for (int i = 0; i < H - 1; ++i) {
+            const ulong2 t = *reinterpret_cast<const ulong2 *>(strip + (wv * STRIP + PAIRS + i) * 2);
+            w[i] = t.x;
+            wp[i] = t.y;
+        }
+    }
 };
 
 // Row-pass round A twiddles through LDS.  In round A the H threads of a row all need the SAME H-1 twiddles
@@ -460,19 +587,18 @@ MK_D void col_forward_finish(u64 (&x)[1 << LOG_H], u64 *lds, const u64 *tw, cons
                              int j, int c, u64 *dst_col, uint32_t r2, Stamper *st = nullptr) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H;
-    u64 w[H - 1], wp[H - 1], w2[H - 1], wp2[H - 1];
-    load_round_twiddles<LOG_H>(tw, tw_sh, 1u, w, wp);  // same for every column: scalar loads
-    radix_forward_any<LOG_H, AR>(x, w, wp, lc);
+    const u64 *strip = lds + TL::WORDS;
+    ColTwB<LOG_H>::stage(lds + TL::WORDS, tw, tw_sh);  // both rounds' twiddles of this wave's rows, read stage by stage
+    wave_lds_sync();
+    radix_forward_staged<LOG_H, AR>(x, [&](int i) { return ColTwB<LOG_H>::pair_a(strip, i); }, lc);
     if (MK_STAMP && st) st->template mark<2>();
-    // second-round twiddles are requested BEFORE the exchange: their L2 latency runs under the barrier wait
-    load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w2, wp2);
 #pragma unroll
     for (int k = 0; k < H; ++k) lds[TL::at(k, j, c)] = x[k];  // row j + H k
     __syncthreads();
     if (MK_STAMP && st) st->template mark<3>();
 #pragma unroll
     for (int k = 0; k < H; ++k) x[k] = lds[TL::at(j, k, c)];  // row H j + k
-    radix_forward_any<LOG_H, AR>(x, w2, wp2, lc);
+    radix_forward_staged<LOG_H, AR>(x, [&](int i) { return ColTwB<LOG_H>::pair_b(strip, j, i); }, lc);
     if (MK_STAMP && st) st->template mark<4>();
 #pragma unroll
     for (int k = 0; k < H; ++k) st_pass(dst_col + (size_t)(H * j + k) * r2, x[k]);  // lazy u64, or doubles on an fp limb
@@ -482,11 +608,11 @@ MK_D void col_forward_finish(u64 (&x)[1 << LOG_H], u64 *lds, const u64 *tw, cons
 // Column pass over R1 = H*H rows: one workgroup = S = 256/H adjacent columns.  Global accesses are
 // S x 8-B row segments (128 B at H = 16); one LDS exchange between the two rounds.
 template <int LOG_H, bool INV, int AR>
-__global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T, const u64 *scale,
+__global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_col_r(NttIo io, NttTables T, const u64 *scale,
                                                            const u64 *scale_sh, int pack) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
-    __shared__ u64 lds[TL::WORDS];
+    __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
     const uint32_t poly = blockIdx.y / io.nsel, sl = nth_set_bit(io.slot_mask, blockIdx.y % io.nsel);
     stagger_start<4, 8>(T.stagger);
     if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;  // block-uniform
@@ -509,33 +635,43 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
         }
         col_forward_finish<LOG_H, AR>(x, lds, tw, tw_sh, lc, j, c, dst, r2);
     } else {
-        u64 w[H - 1], wp[H - 1];
+        ColTwB<LOG_H>::stage(lds + TL::WORDS, tw, tw_sh);
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = ld_pass(src + (size_t)(H * j + k) * r2);  // from the row pass: doubles on an fp limb
-        load_round_twiddles<LOG_H>(tw, tw_sh, (uint32_t)(H + j), w, wp);
-        radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
+        wave_lds_sync();  // the strip is this wave's own
+        const u64 *strip = lds + TL::WORDS;
+        radix_inverse_staged<LOG_H, AR>(x, [&](int i) { return ColTwB<LOG_H>::pair_b(strip, j, i); }, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) lds[TL::at(j, k, c)] = x[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < H; ++k) x[k] = lds[TL::at(k, j, c)];
-        load_round_twiddles<LOG_H>(tw, tw_sh, 1u, w, wp);
-        radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
+        radix_inverse_staged<LOG_H, AR>(x, [&](int i) { return ColTwB<LOG_H>::pair_a(strip, i); }, lc);
         // scale by N^-1 (x folded constant): table entries are (u64, Shoup) or, on an fp limb, (double, double/q)
         const u64 sc = scale ? scale[id] : ((AR == AR_FP) ? dbits(lc.ninv_d) : lc.ninv);
         const u64 sc_sh = scale ? scale_sh[id] : ((AR == AR_FP) ? dbits(lc.ninv_qd) : lc.ninv_sh);
+        if ((AR == AR_FP) && pack == 2) {  // (the output form is decided once, not per word: 16 branches inside the loop otherwise)
 #pragma unroll
-        for (int k = 0; k < H; ++k) {
-            if ((AR == AR_FP) && pack == 2) {
+            for (int k = 0; k < H; ++k) {
                 // canonical residue as a double for k_conv_col's fp64 products: |x| <= 1.33 q -> |s| <= 0.92 q, so one
                 // conditional add lands in [0, q) (the same value fp_to_canonical returns)
                 double sd = fp_mulmod(bitsd(x[k]), bitsd(sc), bitsd(sc_sh), lc.qd);
                 sd = sd < 0.0 ? sd + lc.qd : sd;
                 st_pass(dst + (size_t)(j + H * k) * r2, dbits(sd));
-            } else {
+            }
+        } else if (pack) {
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
                 const u64 v = (AR == AR_FP) ? fp_to_canonical(fp_mulmod(bitsd(x[k]), bitsd(sc), bitsd(sc_sh), lc.qd), lc.qd, lc.qinv)
                                  : shoup_mul(x[k], sc, sc_sh, lc.q);
-                st_pass(dst + (size_t)(j + H * k) * r2, pack ? pack30(v) : v);  // packed halves feed k_conv_col directly
+                st_pass(dst + (size_t)(j + H * k) * r2, pack30(v));  // packed halves feed k_conv_col directly
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                const u64 v = (AR == AR_FP) ? fp_to_canonical(fp_mulmod(bitsd(x[k]), bitsd(sc), bitsd(sc_sh), lc.qd), lc.qd, lc.qinv)
+                                 : shoup_mul(x[k], sc, sc_sh, lc.q);
+                st_pass(dst + (size_t)(j + H * k) * r2, v);
             }
         }
     }
@@ -547,6 +683,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_r(NttIo io, NttTables T
 // inverse transform already multiplied by [(S/s_i)^-1]_{s_i} (folded into its N^-1 scaling).
 // Grid: 1-D, (item, target limb, column tile); the n_out workgroups that share one source tile are made
 // neighbours inside one XCD's queue so the 4 source tiles are fetched from HBM once and then hit in L2.
+constexpr int MAX_CONV_TARGETS = 40;  // = MAX_CONV_OUT (engine.hpp)
 struct ConvIo {
     const u64 *in;      // [items][in_slots][N]
     u64 *out;           // [items][out_slots][N]
@@ -556,7 +693,7 @@ struct ConvIo {
     uint32_t nsel;                   // popcount(target_mask)
 };
 #ifndef MK_CONV_DEPTH
-#define MK_CONV_DEPTH 8  // source slices (outputs) the conversion's loads run ahead
+#define MK_CONV_DEPTH 6  // source slices (outputs) the conversion's loads run ahead
 #endif
 // timing probes of the conversion's source loads (diagnostic builds; results are wrong, the instruction stream is the same):
 // MK_PROBE = 1: every load of a thread reads row j of its source (16 distinct lines per wave instead of 256: L1-resident);
@@ -570,6 +707,9 @@ struct ConvIo {
 #define MK_PROBE_SRC(src, limb_off, row_off) ((u64)threadIdx.x * 0x9E3779B97F4A7C15ull + (limb_off) + (row_off))
 #else
 #define MK_PROBE_SRC(src, limb_off, row_off) (src)[(limb_off) + (row_off)]
+#endif
+#ifndef MK_CL_STORE
+#define MK_CL_STORE 0
 #endif
 #ifndef MK_CONV2_DEPTH
 #define MK_CONV2_DEPTH 4  // the same ring in the two-target kernel k_conv_col2
@@ -654,7 +794,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTable
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
     static_assert(SRCMODE == 0 || N_IN <= 4, "double sources: at most 4 per digit");
-    __shared__ u64 lds[TL::WORDS];
+    __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
     stagger_start<4, (AR == AR_FP ? 10 : 14)>(T.stagger);
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
     const uint32_t groups = io.items * tiles;  // source tiles
@@ -699,6 +839,10 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTable
             uint32_t a0[N_IN], a1[N_IN];
             if (!((AR == AR_FP) && SRCMODE != 0)) conv_split_sources<N_IN, SRCMODE>(p, a0, a1);
             x[k] = conv_output<N_IN, AR, SRCMODE>(p, a0, a1, kc, lc);
+            // the output is materialised here and the refills stay where they are: otherwise the arithmetic sinks to its first
+            // use (the butterflies) while all 16 slices' loads stay at the top, and what does not fit is parked in scratch
+            asm volatile("" : "+v"(x[k]));
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         // 5..8 sources (e.g. alpha = K = 7 at L = 20): same 30-bit columns with the middle one split in two
@@ -734,7 +878,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_conv_col2(ConvIo io, NttTabl
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
     static_assert(N_IN <= 4, "target pairs: at most 4 sources");
-    __shared__ u64 lds[TL::WORDS];
+    __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
     const uint32_t groups = io.items * tiles, ntg = (io.nsel + 1) / 2;
     uint32_t grp, jg;
@@ -784,6 +928,110 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_conv_col2(ConvIo io, NttTabl
     col_forward_finish<LOG_H, AR>(xb, lds, twb, twb_sh, lb, j, c, dst, r2);
 }
 
+// ---- ModUp conversion with the sources in LDS (round 3) ---------------------------------------------------------------
+// k_conv_col gives every target limb of a source tile its own workgroup: 12 workgroups pull the same 4 source tiles
+// (128 KiB) through their CUs' L1 to produce 32 KiB each -- 9.4 GB per step through L2 -- and the in-kernel stamps
+// (profiles/r03_stamps_*) show what that costs: a wave spends 20 000 of its 31 000 cycles in the conversion loop, 4 000 when
+// the same loads hit in L1 (timing probe), for 1 200 cycles of arithmetic; more loads in flight, 16-byte loads and L1
+// sharing between the co-resident workgroups move it by 1-5 %: a CU's L1 fills from L2 at ~16 bytes per clock here and that
+// is the bound.  This kernel reads a source tile ONCE: a workgroup stages the N_IN source limbs of a 4-column tile
+// (256 rows x 32 bytes each) in LDS and its four waves then work through ALL targets of the digit, one (target limb)
+// task at a time per wave -- conversion out of LDS, both rounds of the forward column pass, store.  A wave's 64 lanes are
+// 16 row groups x 4 columns, so the exchange between the rounds stays inside the wave (wave-private LDS tile,
+// wave_lds_sync): after the fill there is no workgroup barrier, waves take tasks from an LDS counter (integer-class
+// targets first: they take longest), and the arithmetic class of a task is a wave-uniform branch.  66 KiB of LDS for 4
+// sources: 2 workgroups per CU.  The 32-byte row segments of neighbouring tiles meet in L2: conv_item_tile makes the
+// tiles of an item consecutive in one XCD's queue.
+constexpr int CL_COLS = 4, CL_BLK = 16 * CL_COLS + 4, CL_TILE = 16 * CL_BLK;  // wave tile: 16 blocks of 16 rows x 4 columns, padded
+struct ConvTargets {
+    uint8_t idx[MAX_CONV_TARGETS];  // indices into cv.dst_*, in the order the tasks are handed out
+    uint32_t n;
+};
+MK_D int cl_at(int blk, int kk, int c) { return blk * CL_BLK + kk * CL_COLS + c; }
+// forward column pass of one wave's 4 columns (see col_forward_finish): rows j + 16 k in x[] on entry
+template <int AR>
+MK_D void col_forward_finish_wave(u64 (&x)[16], u64 *tile, const u64 *tw, const u64 *tw_sh, const LimbConst &lc, int j, int c,
+                                  u64 *dst_col, uint32_t r2) {
+    constexpr int H = 16;
+    u64 w[H - 1], wp[H - 1], w2[H - 1], wp2[H - 1];
+    load_round_twiddles<4>(tw, tw_sh, 1u, w, wp);
+    radix_forward_any<4, AR>(x, w, wp, lc);
+    load_round_twiddles<4>(tw, tw_sh, (uint32_t)(H + j), w2, wp2);
+#pragma unroll
+    for (int k = 0; k < H; ++k) tile[cl_at(k, j, c)] = x[k];  // row j + H k
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < H; ++k) x[k] = tile[cl_at(j, k, c)];  // row H j + k
+    radix_forward_any<4, AR>(x, w2, wp2, lc);
+#if MK_CL_STORE == 0  // 32-byte row segments: plain stores, so that the pieces of a 128-byte line meet in L2
+#pragma unroll
+    for (int k = 0; k < H; ++k) dst_col[(size_t)(H * j + k) * r2] = x[k];
+#elif MK_CL_STORE == 1
+#pragma unroll
+    for (int k = 0; k < H; ++k) st_pass(dst_col + (size_t)(H * j + k) * r2, x[k]);
+#else  // timing probe: one store per thread
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < H; ++k) acc ^= x[k];
+    dst_col[(size_t)(H * j) * r2] = acc;
+#endif
+    wave_lds_sync();  // the tile is read out before the next task writes it
+}
+template <int N_IN, int AR, int SRCMODE, typename CONV>
+MK_D void conv_lds_task(const u64 *srcs, u64 *tile, const CONV &cv, uint32_t jt, const LimbConst &lc, const NttTables &T, int j, int c,
+                        u64 *dst_col, uint32_t r2) {
+    ConvConst<N_IN> kc;
+    conv_consts<N_IN, AR, SRCMODE>(cv, jt, kc);
+    u64 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        u64 p[N_IN];
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i) p[i] = srcs[i * (256 * CL_COLS) + (j + 16 * k) * CL_COLS + c];
+        uint32_t a0[N_IN], a1[N_IN];
+        if (!((AR == AR_FP) && SRCMODE != 0)) conv_split_sources<N_IN, SRCMODE>(p, a0, a1);
+        x[k] = conv_output<N_IN, AR, SRCMODE>(p, a0, a1, kc, lc);
+        asm volatile("" : "+v"(x[k]));
+    }
+    const uint32_t n = 1u << T.log_n, id = cv.dst_id[jt];
+    col_forward_finish_wave<AR>(x, tile, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst_col, r2);
+}
+template <int N_IN, int ARI, typename CONV, int SRCMODE>
+__global__ __launch_bounds__(NTT_THREADS, 2) void k_conv_lds(ConvIo io, NttTables T, CONV cv, ConvTargets tg) {
+    static_assert(N_IN <= 4, "sources of one digit in LDS: at most 4");
+    __shared__ u64 srcs[N_IN * 256 * CL_COLS];
+    __shared__ u64 tiles_[(NTT_THREADS / 64) * CL_TILE];
+    __shared__ uint32_t next_task;
+    const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / CL_COLS;  // 256 rows (log_r1 == 8: host checks)
+    const uint32_t groups = io.items * tiles;
+    uint32_t item, tile;
+    conv_item_tile(blockIdx.x, groups, io.items, tiles, item, tile);
+    const u64 *in = io.in + (size_t)item * io.in_stride + tile * CL_COLS;
+    if (threadIdx.x == 0) next_task = 0;
+    // fill: 16-byte pieces, two per 32-byte row segment; piece p of the tile goes to LDS words 2p, 2p + 1
+#pragma unroll
+    for (int m = 0; m < 2 * N_IN; ++m) {
+        const uint32_t p = threadIdx.x + NTT_THREADS * m, i = m >> 1, row = (p & 511u) >> 1, q = p & 1u;
+        const ulong2 v = *reinterpret_cast<const ulong2 *>(in + (size_t)cv.src_slot[i] * n + (size_t)row * r2 + 2 * q);
+        *reinterpret_cast<ulong2 *>(srcs + 2 * p) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, j = lane >> 2, c = lane & 3;
+    u64 *tile_w = tiles_ + (threadIdx.x >> 6) * CL_TILE;
+    u64 *out = io.out + (size_t)item * io.out_stride + tile * CL_COLS + c;
+    for (;;) {
+        uint32_t task = 0;
+        if (lane == 0) task = atomicAdd(&next_task, 1u);
+        task = (uint32_t)__builtin_amdgcn_readfirstlane((int)task);
+        if (task >= tg.n) break;
+        const uint32_t jt = tg.idx[task];
+        const LimbConst lc = T.limb[cv.dst_id[jt]];
+        u64 *dst_col = out + (size_t)cv.dst_slot[jt] * n;
+        if (lc.fp) conv_lds_task<N_IN, AR_FP, SRCMODE>(srcs, tile_w, cv, jt, lc, T, j, c, dst_col, r2);
+        else conv_lds_task<N_IN, ARI, SRCMODE>(srcs, tile_w, cv, jt, lc, T, j, c, dst_col, r2);
+    }
+}
+
 // ---- ApproxModDown's conversion P -> Q_l for a whole group of clients at once ------------------------------------------
 // The reference converts every client's key-switch result on its own (ApproxModDown inside each ReEncrypt) and adds the
 // re-encryptions afterwards (EvalAdd).  With x_{c,k} the canonical residue mod p_k of client c's coefficient (the inverse
@@ -808,7 +1056,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_icol_sum(const u64 *pc, u64 
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
     static_assert(AR != AR_FP, "P limbs are integer-class");
-    __shared__ u64 lds[TL::WORDS];
+    __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
     stagger_start<3, 40>(T.stagger);
     const uint32_t poly = blockIdx.y / K, k = blockIdx.y % K;
     const uint32_t id = T.L + k;
@@ -821,29 +1069,29 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_icol_sum(const u64 *pc, u64 
     u64 acc[H];
 #pragma unroll
     for (int kk = 0; kk < H; ++kk) acc[kk] = 0;
+    ColTwB<LOG_H>::stage(lds + TL::WORDS, itw0, itw_sh0);  // both rounds' twiddles: the same for every client, staged once
+    wave_lds_sync();
+    const u64 *strip = lds + TL::WORDS;
 #pragma unroll 1
     for (uint32_t cl = 0; cl < n_clients; ++cl) {
         const u64 *src = pc + (size_t)cl * in_cstride + off;
-        u64 x[H], w[H - 1], wp[H - 1];
+        u64 x[H];
         // nothing but the sums is meant to live across the client loop: left alone the compiler computes the H load
         // offsets and loads the 2 (H - 1) round-B twiddles (they do not depend on the client) once in front of the loop
         // and keeps ~90 registers alive across it (52 spilled at 3 waves per SIMD).  Values that are opaque per
         // iteration are recomputed / re-read where they are used (L1 / L2 hits).
         uint32_t r2v = r2;
-        const u64 *itw = itw0, *itw_sh = itw_sh0;
-        asm volatile("" : "+s"(r2v), "+s"(itw), "+s"(itw_sh));
+        asm volatile("" : "+s"(r2v));
 #pragma unroll
         for (int kk = 0; kk < H; ++kk) x[kk] = ld_pass(src + (uint32_t)(H * j + kk) * r2v);
-        load_round_twiddles<LOG_H>(itw, itw_sh, (uint32_t)(H + j), w, wp);
-        radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
+        radix_inverse_staged<LOG_H, AR>(x, [&](int i) { return ColTwB<LOG_H>::pair_b(strip, j, i); }, lc);
         if (cl) __syncthreads();  // the previous client's exchange is read out
 #pragma unroll
         for (int kk = 0; kk < H; ++kk) lds[TL::at(j, kk, c)] = x[kk];
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < H; ++kk) x[kk] = lds[TL::at(kk, j, c)];
-        load_round_twiddles<LOG_H>(itw, itw_sh, 1u, w, wp);
-        radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
+        radix_inverse_staged<LOG_H, AR>(x, [&](int i) { return ColTwB<LOG_H>::pair_a(strip, i); }, lc);
 #pragma unroll
         for (int kk = 0; kk < H; ++kk) acc[kk] += shoup_mul(x[kk], sc, sc_sh, lc.q);  // canonical, as the per-client pass stores it
     }
@@ -861,7 +1109,7 @@ template <int LOG_H, int N_IN, int AR, typename CONV>
 __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_psum(ConvIo io, NttTables T, CONV cv) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
-    __shared__ u64 lds[TL::WORDS];
+    __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
     stagger_start<4, 12>(T.stagger);
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
     const uint32_t groups = io.items * tiles;
@@ -913,6 +1161,8 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_psum(ConvIo io, Ntt
                 acc += fp_mulmod(r, hd[i], hq[i], lc.qd);  // |.| <= 0.76 q each: < 2^53 for 8 sources
             }
             x[kk] = dbits(fp_reduce(acc, lc.qd, lc.qinv));
+            asm volatile("" : "+v"(x[kk]));  // materialised here (see k_conv_col)
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         uint32_t h0[N_IN], h1[N_IN];
@@ -930,6 +1180,8 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_psum(ConvIo io, Ntt
                     mac_cols(acc, a0, a1, h0[i], h1[i]);
                 }
                 x[kk] = AR == AR_PM ? pm_reduce_cols(acc, pm_consts(lc)) : reduce_cols_lazy(acc, lc);  // < 4q
+                asm volatile("" : "+v"(x[kk]));
+                __builtin_amdgcn_sched_barrier(0);
             } else {
                 Cols4 acc{0, 0, 0, 0};
 #pragma unroll
@@ -955,7 +1207,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_switch_col(const u64 *last, u64
                                                             u64 q_last, unsigned long long target_mask) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
-    __shared__ u64 lds[TL::WORDS];
+    __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
     stagger_start<4, 8>(T.stagger);
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2;
     const uint32_t sl = nth_set_bit(target_mask, blockIdx.y), item = blockIdx.z;  // remaining Q limb: slot == limb id

@@ -484,6 +484,7 @@ def test_reencrypt_sum(ctxs, name, nl, C, B):
                                  {"MKCKKS_QSUM_PIPE": "1"},       # k_qsum3p_fp: operand loads software-pipelined, 3 waves
                                  {"MKCKKS_QSUM_PIPE": "2"},       # ... 2 waves, own-digit tiles a whole phase ahead
                                  {"MKCKKS_QSUM_PIPE": "1", "MKCKKS_QSUM_GROUP": "2"},
+                                 {"MKCKKS_CONV_LDS": "1"},        # ModUp conversion out of LDS, all targets of a digit per workgroup (k_conv_lds)
                                  {"MKCKKS_CONV_PAIR2": "3"},      # ModUp conversion: two targets of a class per workgroup (k_conv_col2)
                                  {"MKCKKS_CONV_PAIR2": "1"},
                                  {"MKCKKS_CU_AFFINE": "0"},       # plain XCD-aware placement of the workgroups that share tiles

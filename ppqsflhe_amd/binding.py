@@ -53,6 +53,16 @@ SYMBOLS = {
     "mkckks_dev_free": (_int, [_vp, _vp]),
     "mkckks_upload": (_int, [_vp, _vp, _vp, _sz]),
     "mkckks_download": (_int, [_vp, _vp, _vp, _sz]),
+    "mkckks_host_alloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
+    "mkckks_host_free": (_int, [_vp, _vp]),
+    "mkckks_upload_async": (_int, [_vp, _vp, _vp, _sz, C.POINTER(C.c_uint64)]),
+    "mkckks_download_async": (_int, [_vp, _vp, _vp, _sz, C.POINTER(C.c_uint64)]),
+    "mkckks_copy_done": (_int, [_vp, C.c_uint64, C.POINTER(_int)]),
+    "mkckks_copy_wait": (_int, [_vp, C.c_uint64]),
+    "mkckks_fence_uploads": (_int, [_vp]),
+    "mkckks_fence_compute": (_int, [_vp]),
+    "mkckks_count_noncanonical": (_int, [_vp, _vp, _u32, _u32, C.POINTER(C.c_uint64)]),
+    "mkckks_debug_stamps": (_int, [_vp, _vp, _u32, C.POINTER(_sz)]),
     "mkckks_ntt_forward_batch": (_int, [_vp, _vp, _u32, _u32, _int]),
     "mkckks_ntt_inverse_batch": (_int, [_vp, _vp, _u32, _u32, _int]),
     "mkckks_eval_add_batch": (_int, [_vp, _vp, _vp, _vp, _u32, _u32]),
@@ -301,6 +311,50 @@ class Context:
 
     def reduce_mod(self, ct, n_ct, nl, n_terms):
         self._check(self._L.mkckks_reduce_mod_batch(self._h, _ptr(ct), n_ct, nl, n_terms))
+
+    # ---- I/O pipeline (pinned host buffers, asynchronous copies with tickets, fences; include/mkckks.h)
+    def host_alloc(self, nbytes):
+        """Pinned host buffer as a numpy uint8 array (free it with host_free(array))."""
+        p = C.c_void_p()
+        self._check(self._L.mkckks_host_alloc(self._h, nbytes, C.byref(p)))
+        arr = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p.value))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        self._check(self._L.mkckks_host_free(self._h, self._pinned.pop(arr.ctypes.data)))
+
+    def upload_async(self, dev, host_arr, nbytes=None):
+        t = C.c_uint64()
+        self._check(self._L.mkckks_upload_async(self._h, _ptr(dev), host_arr.ctypes.data,
+                                                host_arr.nbytes if nbytes is None else nbytes, C.byref(t)))
+        return t.value
+
+    def download_async(self, host_arr, dev, nbytes=None):
+        t = C.c_uint64()
+        self._check(self._L.mkckks_download_async(self._h, host_arr.ctypes.data, _ptr(dev),
+                                                  host_arr.nbytes if nbytes is None else nbytes, C.byref(t)))
+        return t.value
+
+    def copy_done(self, ticket):
+        d = C.c_int()
+        self._check(self._L.mkckks_copy_done(self._h, ticket, C.byref(d)))
+        return bool(d.value)
+
+    def copy_wait(self, ticket):
+        self._check(self._L.mkckks_copy_wait(self._h, ticket))
+
+    def fence_uploads(self):
+        self._check(self._L.mkckks_fence_uploads(self._h))
+
+    def fence_compute(self):
+        self._check(self._L.mkckks_fence_compute(self._h))
+
+    def count_noncanonical(self, ct, n_ct, nl):
+        c = C.c_uint64()
+        self._check(self._L.mkckks_count_noncanonical(self._h, _ptr(ct), n_ct, nl, C.byref(c)))
+        return c.value
 
     # ---- RCCL exchange of the per-GPU partial sums (behind the C-ABI; librccl resolved by the library)
     def comm_unique_id(self):

@@ -480,35 +480,10 @@ Knobs Knobs::from_env() {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 64) k.qsum_group = (uint32_t)v;
     }
-    if (const char *e = std::getenv("MKCKKS_QSUM_GEOM")) {
-        const int v = std::atoi(e);
-        if (v == 2 || v == 3 || v == 4) k.qsum_geom = v;
-    }
-    if (const char *e = std::getenv("MKCKKS_STAGGER")) {
-        const int v = std::atoi(e);
-        if (v >= 0 && v <= 1000) k.stagger = (uint32_t)v;
-    }
-    if (const char *e = std::getenv("MKCKKS_QSUM_PIPE")) {
-        const int v = std::atoi(e);
-        if (v >= 0 && v <= 2) k.qsum_pipe = v;
-    }
     k.cu_affine = env_flag("MKCKKS_CU_AFFINE", k.cu_affine);
-    k.conv_lds = env_flag("MKCKKS_CONV_LDS", k.conv_lds);
-    if (const char *e = std::getenv("MKCKKS_CONV_PAIR2")) {
-        const int v = std::atoi(e);
-        if (v >= 0 && v <= 3) k.conv_pair2 = (uint32_t)v;
-    }
     k.generic_ntt = env_flag("MKCKKS_GENERIC_NTT", k.generic_ntt);
     k.no_pm = env_flag("MKCKKS_NO_PM", k.no_pm);
     k.no_fp64 = env_flag("MKCKKS_NO_FP64", k.no_fp64);
-    k.fuse_inner = env_flag("MKCKKS_FUSE_INNER", k.fuse_inner);
-    k.fuse_inner_int = env_flag("MKCKKS_FUSE_INNER_INT", k.fuse_inner_int);
-    k.fuse_p_inverse = env_flag("MKCKKS_FUSE_P_INVERSE", k.fuse_p_inverse);
-    k.sum_pair = env_flag("MKCKKS_SUM_PAIR", k.sum_pair);
-    k.row3x = env_flag("MKCKKS_ROW3X", k.row3x);
-    k.one_lane = env_flag("MKCKKS_SUM_ONE_LANE", k.one_lane);
-    k.conv_fp = env_flag("MKCKKS_CONV_FP", k.conv_fp);
-    k.qsum = env_flag("MKCKKS_QSUM", k.qsum);
     return k;
 }
 
@@ -550,19 +525,13 @@ Engine::Engine(const ParamSet &ps, int device) : ps_(ps), device_(device), knobs
         ps_.limb[i].pm_c = pm ? (uint32_t)(((u64)1 << ps_.limb[i].k) - ps_.moduli[i]) : 0u;
     }
     tabs_.h_fp_of = fp_of_.data();
-    tabs_.stagger = knobs_.stagger;
     tabs_.cu_affine = knobs_.cu_affine ? 1u : 0u;
-    tabs_.conv_pair2 = knobs_.conv_pair2;
-    tabs_.conv_lds = knobs_.conv_lds ? 1u : 0u;
     tabs_.stamps = nullptr;
     if (MK_STAMP && env_flag("MKCKKS_STAMPS", false)) {  // diagnostic build: phase stamps of the hot kernels (tools/stamps.py)
         MK_HIP(hipMalloc(&d_stamps_, (size_t)STAMP_REGIONS * STAMP_REGION * sizeof(unsigned long long)));
         MK_HIP(hipMemset(d_stamps_, 0, (size_t)STAMP_REGIONS * STAMP_REGION * sizeof(unsigned long long)));
         tabs_.stamps = d_stamps_;
     }
-    MK_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));  // second client lane of reencrypt_sum
-    MK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-    MK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     MK_HIP(hipMalloc(&d_limb_, D * sizeof(LimbConst)));
     MK_HIP(hipMemcpy(d_limb_, ps_.limb.data(), D * sizeof(LimbConst), hipMemcpyHostToDevice));
     const size_t tbytes = (size_t)D * n * sizeof(u64);
@@ -646,9 +615,6 @@ Engine::~Engine() {
         for (uint32_t i = 0; i < COPY_RING; ++i) (void)hipEventDestroy(copy_ev_[i]);
         (void)hipEventDestroy(ev_fence_);
     }
-    if (side_stream_) (void)hipStreamDestroy(side_stream_);
-    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-    if (ev_join_) (void)hipEventDestroy(ev_join_);
 }
 
 Lanes Engine::lanes() const { return Lanes{stream_}; }
@@ -985,8 +951,6 @@ static void launch_col(const NttIo &io0, const NttTables &T, uint32_t n_polys, c
 }
 
 static bool row_tail_supported(const NttTables &T) { return fast_row(T.log_r2, 1u << T.log_r1) != 0; }
-// the fused n-client sum kernel exists for every radix row kernel (two rounds, or three rounds of radix 8)
-static bool row_sum_supported(const NttTables &T) { return fast_row(T.log_r2, 1u << T.log_r1) != 0; }
 
 template <bool INV>
 static void launch_row(const NttIo &io0, const NttTables &T, uint32_t n_polys, const TailArgs &tail, const Lanes &ln,
@@ -1064,24 +1028,6 @@ static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inve
 template <int LOG_H, int N_IN, int SRCMODE>
 static void launch_conv_col_n(const ConvIo &io, const ConvIo &iof, const dim3 &grid, const dim3 &gridf, const NttTables &T,
                               const DevConv &cv, const Lanes &ln) {
-    if constexpr (N_IN <= 4 && LOG_H >= 3) {
-        if (T.conv_pair2) {  // two targets of a class per workgroup: half the source traffic through each CU's L1
-            const uint32_t per = grid.x / (io.nsel ? io.nsel : 1), perf = gridf.x / (iof.nsel ? iof.nsel : 1);
-            if (io.nsel && (T.conv_pair2 & 1)) with_int_arith(T, [&](auto ar) {
-                k_conv_col2<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE>
-                    <<<dim3(per * ((io.nsel + 1) / 2)), NTT_THREADS, 0, ln.main>>>(io, T, cv);
-            });
-            else if (io.nsel) with_int_arith(T, [&](auto ar) {
-                k_conv_col<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE>
-                    <<<grid, NTT_THREADS, 0, ln.main>>>(io, T, cv);
-            });
-            if (iof.nsel && (T.conv_pair2 & 2))
-                k_conv_col2<LOG_H, N_IN, AR_FP, DevConv, SRCMODE><<<dim3(perf * ((iof.nsel + 1) / 2)), NTT_THREADS, 0, ln.main>>>(iof, T, cv);
-            else if (iof.nsel)
-                k_conv_col<LOG_H, N_IN, AR_FP, DevConv, SRCMODE><<<gridf, NTT_THREADS, 0, ln.main>>>(iof, T, cv);
-            return;
-        }
-    }
     launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
         [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
             k_conv_col<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE>
@@ -1182,36 +1128,8 @@ static void launch_icol_sum(const u64 *pc, u64 *psum, const NttTables &T, const 
     }
     MK_HIP(hipGetLastError());
 }
-// ModUp conversion with the source tile staged in LDS and every target of the digit done by one workgroup (k_conv_lds);
-// needs 256-point columns, at most 4 sources and both arithmetic classes wanted.  Task order: integer-class targets first.
-template <int N_IN>
-static void launch_conv_lds_n(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s, int srcmode) {
-    ConvTargets tg{};
-    for (int pass = 0; pass < 2; ++pass)
-        for (uint32_t j = 0; j < cv.n_out; ++j)
-            if ((T.h_fp_of[cv.dst_id[j]] != 0) == (pass == 1)) tg.idx[tg.n++] = (uint8_t)j;
-    const dim3 grid(io.items * ((1u << T.log_r2) / CL_COLS));
-    with_int_arith(T, [&](auto ar) {
-        constexpr int ARI = decltype(ar)::value;
-        if (srcmode == 1) k_conv_lds<N_IN, ARI, DevConv, 1><<<grid, NTT_THREADS, 0, s>>>(io, T, cv, tg);
-        else if (srcmode == 2) k_conv_lds<N_IN, ARI, DevConv, (N_IN > 1 ? 2 : 0)><<<grid, NTT_THREADS, 0, s>>>(io, T, cv, tg);
-        else k_conv_lds<N_IN, ARI, DevConv, 0><<<grid, NTT_THREADS, 0, s>>>(io, T, cv, tg);
-    });
-}
-static bool launch_conv_lds(const ConvIo &io, const NttTables &T, const DevConv &cv, hipStream_t s, int srcmode) {
-    if (T.log_r1 != 8 || cv.n_in > 4 || cv.n_out > (uint32_t)MAX_CONV_TARGETS) return false;
-    switch (cv.n_in) {
-        case 1: launch_conv_lds_n<1>(io, T, cv, s, srcmode); break;
-        case 2: launch_conv_lds_n<2>(io, T, cv, s, srcmode); break;
-        case 3: launch_conv_lds_n<3>(io, T, cv, s, srcmode); break;
-        default: launch_conv_lds_n<4>(io, T, cv, s, srcmode); break;
-    }
-    MK_HIP(hipGetLastError());
-    return true;
-}
 static bool launch_conv_col(const ConvIo &io, const NttTables &T, const DevConv &cv, const Lanes &s, int srcmode = 0,
                             unsigned classes = 3) {
-    if (T.conv_lds && classes == 3 && launch_conv_lds(io, T, cv, s.main, srcmode)) return true;
     switch (fast_log_h(T.log_r1, 1u << T.log_r2)) {
         case 4: launch_conv_col_h<4>(io, T, cv, s, srcmode, classes); break;
         case 3: launch_conv_col_h<3>(io, T, cv, s, srcmode, classes); break;
@@ -1425,7 +1343,7 @@ void Engine::modup_core(const u64 *c1, size_t c1_stride, u64 *coef, u64 *dig, ui
     const size_t dstride = (size_t)nparts * ext * n;
     // interchange format of the coefficient-form digits: fp64-class limbs as canonical doubles when every digit is
     // "all fp64-class" or "q_0 first, then fp64-class" (k_conv_col's SRCMODE 1 / 2), else packed halves throughout
-    bool doubles = fused && knobs_.conv_fp && tabs_.has_fp && fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) >= 3;
+    bool doubles = fused && tabs_.has_fp && fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) >= 3;
     for (uint32_t part = 0; part < nparts && doubles; ++part) {
         const DevConv &cv = modup_conv(nl, part);
         if (conv_src_mode(cv) < 0 || (conv_src_mode(cv) != 0 && cv.n_in > 4)) doubles = false;
@@ -1657,9 +1575,9 @@ bool Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u
     unsigned long long fp_mask = 0, all_mask = ext >= 64 ? ~0ull : ((1ull << ext) - 1);
     for (uint32_t i = 0; i < nl; ++i)
         if (tabs_.h_fp_of[i]) fp_mask |= 1ull << i;
-    const bool fuse = knobs_.fuse_inner && fp_mask != 0 && (row_h == 3 || row_h == 4 || row_h == 9) &&
+    const bool fuse = fp_mask != 0 && (row_h == 3 || row_h == 4 || row_h == 9) &&
                       fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0;
-    const bool fuse_int = fuse && (row_h == 4 || row_h == 9) && knobs_.fuse_inner_int;  // +1.3 % at C3
+    const bool fuse_int = fuse && (row_h == 4 || row_h == 9);  // +1.3 % at C3
     {
         struct Reset {  // cleared on every exit path: the public ModUp entry point must never inherit it
             bool &flag;
@@ -1672,14 +1590,13 @@ bool Engine::keyswitch_digits(const u64 *c1, size_t ct_stride, const u64 *evk, u
         InnerArgs a{dig, c1, evk, til, ct_stride, nl, ext, D, ps_.alpha, cnt, fp_mask,
                     (uint32_t)__builtin_popcountll(fp_mask)};
         if (row_h == 9) launch_row3_inner_fp_n<3>(a, tabs_, nparts, stream_);
-        else if (row_h == 4 && knobs_.row3x) launch_row3_inner_fp_n<2>(a, tabs_, nparts, stream_);
         else if (row_h == 4) launch_row_inner_fp_n<4>(a, tabs_, nparts, stream_);
         else launch_row_inner_fp_n<3>(a, tabs_, nparts, stream_);
     }
     const unsigned long long mask = fuse ? (all_mask & ~fp_mask) : all_mask;
     if (fuse_int) {  // integer limbs: row pass + inner product in one three-round kernel as well
         InnerArgs a{dig, c1, evk, til, ct_stride, nl, ext, D, ps_.alpha, cnt, mask, (uint32_t)__builtin_popcountll(mask)};
-        u64 *pc_fused = (pc && knobs_.fuse_p_inverse) ? pc : nullptr;
+        u64 *pc_fused = pc;
         if (row_h == 9) launch_row3_inner_int_n<3>(a, tabs_, nparts, ps_.L, pc_fused, ps_.K, stream_);
         else launch_row3_inner_int_n<2>(a, tabs_, nparts, ps_.L, pc_fused, ps_.K, stream_);
         MK_HIP(hipGetLastError());
@@ -1714,66 +1631,6 @@ void Engine::reencrypt_chunk(const u64 *ct, const u64 *evk, u64 *out, uint32_t c
     moddown_core(til, pc, conv, out, (size_t)nl * n, ct, ct_stride, 2 * cnt, nl, accumulate, p_rows);
 }
 
-// classes: bit 0 = integer-class limbs, bit 1 = fp64-class limbs
-template <int LOGC>
-static void launch_row3_tail_sum(SumArgs a, const NttTables &T, hipStream_t s, unsigned classes = 3) {
-    const uint32_t tiles = (1u << T.log_r1) / RowT<LOGC>::ROWS;
-    SumArgs ai = a, af = a;
-    ai.slot_mask = af.slot_mask = 0;
-    for (uint32_t i = 0; i < a.nl; ++i) (T.h_fp_of[i] ? af.slot_mask : ai.slot_mask) |= 1ull << i;
-    ai.nsel = (uint32_t)__builtin_popcountll(ai.slot_mask);
-    af.nsel = (uint32_t)__builtin_popcountll(af.slot_mask);
-    if (ai.nsel && (classes & 1)) with_int_arith(T, [&](auto ar) {
-        k_row3_tail_sum<decltype(ar)::value, LOGC>
-            <<<dim3(tiles * ai.nsel * a.n_polys), NTT_THREADS, 0, s>>>(ai, T);
-    });
-    if (af.nsel && (classes & 2)) k_row3_tail_sum<AR_FP, LOGC><<<dim3(tiles * af.nsel * a.n_polys), NTT_THREADS, 0, s>>>(af, T);
-}
-
-template <int LOG_H>
-static void launch_row_tail_sum(SumArgs a, const NttTables &T, bool pair, hipStream_t s, unsigned classes = 3) {
-    const uint32_t tiles = (1u << T.log_r1) / (256u >> LOG_H);
-    SumArgs ai = a, af = a;
-    ai.slot_mask = af.slot_mask = 0;
-    for (uint32_t i = 0; i < a.nl; ++i) (T.h_fp_of[i] ? af.slot_mask : ai.slot_mask) |= 1ull << i;
-    ai.nsel = (uint32_t)__builtin_popcountll(ai.slot_mask);
-    af.nsel = (uint32_t)__builtin_popcountll(af.slot_mask);
-    if (!(classes & 1)) ai.nsel = 0;
-    if (!(classes & 2)) af.nsel = 0;
-    const dim3 gi(tiles * ai.nsel * a.n_polys), gf(tiles * af.nsel * a.n_polys);
-    // two clients per workgroup iteration (shared twiddle fetches, two dependency chains): the default; 2 waves per
-    // SIMD either way (212 VGPRs, no spills; measured equal to 3 waves, faster than 4)
-    if (pair && LOG_H == 4) {
-        if (ai.nsel) with_int_arith(T, [&](auto ar) {
-            k_row_tail_sum2<LOG_H, decltype(ar)::value>
-                <<<gi, NTT_THREADS, 0, s>>>(ai, T);
-        });
-        if (af.nsel) k_row_tail_sum2<LOG_H, AR_FP><<<gf, NTT_THREADS, 0, s>>>(af, T);
-    } else {
-        if (a.til_compact) throw std::logic_error("compact accumulators need the paired sum kernel");
-        if (ai.nsel) with_int_arith(T, [&](auto ar) {
-            k_row_tail_sum<LOG_H, decltype(ar)::value, 2>
-                <<<gi, NTT_THREADS, 0, s>>>(ai, T);
-        });
-        if (af.nsel) k_row_tail_sum<LOG_H, AR_FP, 2><<<gf, NTT_THREADS, 0, s>>>(af, T);
-    }
-}
-
-template <int LOG_H>
-static void launch_qsum_fp(const QSumArgs &a, const NttTables &T, uint32_t nparts, hipStream_t s) {
-    const uint32_t tiles = (1u << T.log_r1) / (256u >> LOG_H);
-    const dim3 grid(tiles * a.nsel * a.cnt);
-    switch (nparts) {
-        case 1: k_qsum_fp<LOG_H, 1><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 2: k_qsum_fp<LOG_H, 2><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 3: k_qsum_fp<LOG_H, 3><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 4: k_qsum_fp<LOG_H, 4><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 5: k_qsum_fp<LOG_H, 5><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 6: k_qsum_fp<LOG_H, 6><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
-    }
-}
-
 template <int LOGC, int MINW>
 static void launch_qsum3_fp(const QSumArgs &a, const NttTables &T, uint32_t nparts, hipStream_t s) {
     const uint32_t tiles = (1u << T.log_r1) / RowT<LOGC>::ROWS;
@@ -1786,20 +1643,6 @@ static void launch_qsum3_fp(const QSumArgs &a, const NttTables &T, uint32_t npar
         case 5: k_qsum3_fp<5, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
         case 6: k_qsum3_fp<6, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
         default: throw std::invalid_argument("more than 6 key-switch digits unsupported");
-    }
-}
-
-template <int LOGC, int MINW>
-static void launch_qsum3p_fp(const QSumArgs &a, const NttTables &T, uint32_t nparts, hipStream_t s) {
-    const uint32_t tiles = (1u << T.log_r1) / RowT<LOGC>::ROWS;
-    const dim3 grid(tiles * a.nsel * a.cnt);
-    switch (nparts) {
-        case 2: k_qsum3p_fp<2, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 3: k_qsum3p_fp<3, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 4: k_qsum3p_fp<4, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 5: k_qsum3p_fp<5, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        case 6: k_qsum3p_fp<6, LOGC, MINW><<<grid, NTT_THREADS, 0, s>>>(a, T); break;
-        default: throw std::invalid_argument("pipelined sum kernel: 2..6 key-switch digits");
     }
 }
 
@@ -1821,9 +1664,6 @@ const u64 *Engine::p_doubles() {
 // the merged n-client flow needs: radix column kernels (64- or 256-point columns), 256- or 512-point rows (k_qsum3_fp,
 // k_row3_inner_int and the fused tail + sum kernels exist for them), fp64-class Q limbs, integer-class P limbs
 bool Engine::qsum_ok(uint32_t nl) const {
-    if (!knobs_.qsum || !knobs_.fuse_inner || !knobs_.fuse_inner_int || !knobs_.fuse_p_inverse || !knobs_.sum_pair ||
-        knobs_.row3x)
-        return false;
     const int row_h = fast_row(tabs_.log_r2, 1u << tabs_.log_r1);
     if ((row_h != 4 && row_h != 9) || fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) < 3) return false;
     for (uint32_t k = 0; k < ps_.K; ++k)
@@ -1838,8 +1678,8 @@ bool Engine::qsum_ok(uint32_t nl) const {
 //   ModUp of c1 -> converted digits (column-passed)                          modup_core
 //   P limbs: row pass + eval-key inner product + inverse row pass            k_row3_inner_int<.., true>
 //   ApproxModDown's conversion P -> Q_l (column-passed)                      moddown_convert
-//   integer-class Q limbs (q_0): inner product, then row pass + tail + sum   k_row3_inner_int<.., false>, k_row_tail_sum2
-//   fp64-class Q limbs: everything that is left, summed over clients        k_qsum_fp
+//   integer-class Q limbs (q_0): inner product, then row pass + tail + sum   k_row3_inner_int<.., false>, k_row3_tail_once
+//   fp64-class Q limbs: everything that is left, summed over clients        k_qsum3_fp
 void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uint32_t n_clients, uint32_t n_ct,
                                   uint32_t nl) {
     const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, nparts = ps_.num_parts(nl), D = ps_.D;
@@ -1927,79 +1767,10 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
             }
             QSumArgs qa{dig, convsum, ct0, evk0, out + (size_t)b0 * ct_words, pq, ct_cstride, ct_words, evk_words, ct_words,
                         gc, cnt, nl, ext, D, ps_.alpha, fp_mask, (uint32_t)__builtin_popcountll(fp_mask), g0 != 0 ? 1u : 0u};
-            if (knobs_.qsum_pipe && nparts >= 2 && knobs_.qsum_geom == 3) {  // operand loads software-pipelined
-                if (wide_rows) {
-                    if (knobs_.qsum_pipe == 2) launch_qsum3p_fp<3, 2>(qa, tabs_, nparts, main);
-                    else launch_qsum3p_fp<3, 3>(qa, tabs_, nparts, main);
-                } else {
-                    if (knobs_.qsum_pipe == 2) launch_qsum3p_fp<2, 2>(qa, tabs_, nparts, main);
-                    else launch_qsum3p_fp<2, 3>(qa, tabs_, nparts, main);
-                }
-            } else if (wide_rows) launch_qsum3_fp<3, 3>(qa, tabs_, nparts, main);
-            else if (knobs_.qsum_geom == 2) launch_qsum_fp<4>(qa, tabs_, nparts, main);
-            else if (knobs_.qsum_geom == 4) launch_qsum3_fp<2, 2>(qa, tabs_, nparts, main);
+            if (wide_rows) launch_qsum3_fp<3, 3>(qa, tabs_, nparts, main);
             else launch_qsum3_fp<2, 3>(qa, tabs_, nparts, main);
             MK_HIP(hipGetLastError());
         }
-    }
-}
-
-// per-client flow: everything up to the column pass of ModDown runs per client (two clients in flight on two streams),
-// the last row pass + tail + sum is one kernel over all clients (k_row_tail_sum / k_row_tail_sum2 / k_row3_tail_sum)
-void Engine::reencrypt_sum_lanes(const u64 *cts, const u64 *evks, u64 *out, uint32_t n_clients, uint32_t n_ct, uint32_t nl) {
-    const uint32_t n = ps_.n, K = ps_.K, ext = nl + K, nparts = ps_.num_parts(nl), D = ps_.D;
-    const size_t ct_words = (size_t)2 * nl * n, evk_words = (size_t)ps_.beta * 2 * D * n;
-    const u64 *pinv = p_inverse(nl);
-    const int log_h = fast_row(tabs_.log_r2, 1u << tabs_.log_r1);  // 9: three-round kernels on 512-point rows
-    for (uint32_t b0 = 0; b0 < n_ct; b0 += knobs_.chunk) {
-        const uint32_t cnt = n_ct - b0 < knobs_.chunk ? n_ct - b0 : knobs_.chunk;
-        // arena: per client {til, conv}; per lane {coef, dig, pc}
-        const size_t w_til = (size_t)cnt * 2 * ext * n, w_conv = (size_t)cnt * 2 * nl * n;
-        const size_t w_coef = (size_t)cnt * nl * n, w_dig = (size_t)cnt * nparts * ext * n, w_pc = (size_t)cnt * 2 * K * n;
-        const size_t w_lane = w_coef + w_dig + w_pc;
-        // two clients in flight on two streams (Knobs::one_lane serialises them, e.g. to compare the HIP-event step time
-        // with the sum of rocprof kernel durations); 3 and 4 lanes were measured slower (-1.5 % / -5 %)
-        const uint32_t n_lanes = (side_stream_ != nullptr && n_clients > 1 && !knobs_.one_lane) ? 2u : 1u;
-        u64 *ws = workspace((size_t)n_clients * (w_til + w_conv) + (size_t)n_lanes * w_lane);
-        u64 *til0 = ws, *conv0 = til0 + (size_t)n_clients * w_til, *lane0 = conv0 + (size_t)n_clients * w_conv;
-        hipStream_t main = stream_;
-        struct Restore {  // the per-client helpers launch on stream_; put it back on every exit path
-            hipStream_t &ref, saved;
-            ~Restore() { ref = saved; }
-        } restore{stream_, main};
-        hipStream_t lane_stream[2] = {main, side_stream_};
-        if (n_lanes == 2) {
-            MK_HIP(hipEventRecord(ev_fork_, main));
-            MK_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
-        }
-        for (uint32_t c = 0; c < n_clients; ++c) {
-            const uint32_t lane = c % n_lanes;
-            stream_ = lane_stream[lane];  // the helpers below launch on stream_
-            u64 *coef = lane0 + (size_t)lane * w_lane, *dig = coef + w_coef, *pc = dig + w_dig;
-            u64 *til = til0 + (size_t)c * w_til, *conv = conv0 + (size_t)c * w_conv;
-            const u64 *ct = cts + ((size_t)c * n_ct + b0) * ct_words, *evk = evks + (size_t)c * evk_words;
-            const u64 *c1 = ct + (size_t)nl * n;
-            const bool p_rows = keyswitch_digits(c1, ct_words, evk, coef, dig, til, pc, cnt, nl);
-            // ModDown up to the column pass of the converted limbs
-            moddown_convert(til, pc, conv, 2 * cnt, nl, p_rows);
-        }
-        stream_ = main;
-        if (n_lanes == 2) {  // the sum waits for the side lane
-            MK_HIP(hipEventRecord(ev_join_, side_stream_));
-            MK_HIP(hipStreamWaitEvent(main, ev_join_, 0));
-        }
-        SumArgs a{conv0, til0, cts + (size_t)b0 * ct_words, out + (size_t)b0 * ct_words, pinv, pinv + nl,
-                  w_conv, w_til, (size_t)n_ct * ct_words, ct_words, n_clients, nl, ext, 2 * cnt, 0, 0, 0u};
-        switch (log_h) {
-            case 9: launch_row3_tail_sum<3>(a, tabs_, main); break;
-            case 4:
-                if (knobs_.row3x) launch_row3_tail_sum<2>(a, tabs_, main);
-                else launch_row_tail_sum<4>(a, tabs_, knobs_.sum_pair, main);
-                break;
-            case 3: launch_row_tail_sum<3>(a, tabs_, knobs_.sum_pair, main); break;
-            default: launch_row_tail_sum<2>(a, tabs_, knobs_.sum_pair, main); break;
-        }
-        MK_HIP(hipGetLastError());
     }
 }
 
@@ -2008,14 +1779,13 @@ void Engine::reencrypt_sum(const u64 *cts, const u64 *evks, u64 *out, uint32_t n
     check_nl(nl);
     if (!n_clients || !n_ct) return;
     const size_t ct_words = (size_t)2 * nl * ps_.n, evk_words = (size_t)ps_.beta * 2 * ps_.D * ps_.n;
-    const bool fused = fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) != 0 && row_sum_supported(tabs_);
-    if (!fused) {  // ring sizes without the fused sum kernel: plain loop with the accumulating tail
-        for (uint32_t c = 0; c < n_clients; ++c)
-            reencrypt(cts + (size_t)c * n_ct * ct_words, evks + (size_t)c * evk_words, out, n_ct, nl, c != 0);
+    if (qsum_ok(nl)) {  // N = 2^14, 2^16, 2^17 with fp64-class Q limbs: every phase one launch over all (client, index) items
+        reencrypt_sum_merged(cts, evks, out, n_clients, n_ct, nl);
         return;
     }
-    if (qsum_ok(nl)) reencrypt_sum_merged(cts, evks, out, n_clients, n_ct, nl);
-    else reencrypt_sum_lanes(cts, evks, out, n_clients, n_ct, nl);
+    // other ring sizes / arithmetic classes: one re-encryption per client with the accumulating tail
+    for (uint32_t c = 0; c < n_clients; ++c)
+        reencrypt(cts + (size_t)c * n_ct * ct_words, evks + (size_t)c * evk_words, out, n_ct, nl, c != 0);
 }
 
 void Engine::reencrypt(const u64 *ct, const u64 *evk, u64 *out, uint32_t n_ct, uint32_t nl, bool accumulate) {

@@ -56,25 +56,10 @@ struct Knobs {
     uint32_t chunk = 16;         // MKCKKS_CHUNK: ciphertexts per workspace chunk
     uint32_t qsum_group = 8;     // MKCKKS_QSUM_GROUP: clients per pass of the merged n-client flow (one forward transform of
                                  // the summed ModDown conversions per group: 8 is +2.7 % against 4, 2 is -6.6 %)
-    uint32_t stagger = 0;        // MKCKKS_STAGGER: start-phase stagger of each pass's first generation of workgroups, percent of
-                                 // the built-in steps (ntt_radix.hpp: stagger_start); 0 = all workgroups start together
-    bool conv_lds = false;       // MKCKKS_CONV_LDS=1: ModUp conversion with the source tile in LDS, all targets per workgroup (k_conv_lds)
-    uint32_t conv_pair2 = 0;     // MKCKKS_CONV_PAIR2: bit 0 / bit 1 = two integer-class / fp64-class targets per workgroup in the ModUp
-                                 // conversion (k_conv_col2)
     bool cu_affine = true;       // MKCKKS_CU_AFFINE=0: plain XCD-aware placement; default: workgroups that share operand tiles on the same CU (group_member)
-    int qsum_pipe = 0;           // MKCKKS_QSUM_PIPE: 1 / 2 = k_qsum3p_fp (operand loads software-pipelined) at 3 / 2 waves per SIMD
-    int qsum_geom = 3;           // MKCKKS_QSUM_GEOM: 3 = three-round k_qsum3_fp (3 waves per SIMD), 2 = two-round k_qsum_fp
     bool generic_ntt = false;    // MKCKKS_GENERIC_NTT=1: LDS-stage kernels for both passes
     bool no_pm = false;          // MKCKKS_NO_PM=1: Shoup butterflies on the integer limbs instead of the pseudo-Mersenne ones
     bool no_fp64 = false;        // MKCKKS_NO_FP64=1: integer arithmetic on every limb
-    bool fuse_inner = true;      // MKCKKS_FUSE_INNER=0: separate row pass + inner product (all limbs)
-    bool fuse_inner_int = true;  // MKCKKS_FUSE_INNER_INT=0: ... for the integer limbs only
-    bool fuse_p_inverse = true;  // MKCKKS_FUSE_P_INVERSE=0: P-limb accumulators through HBM
-    bool sum_pair = true;        // MKCKKS_SUM_PAIR=0: one client per iteration in the fused sum kernel
-    bool row3x = false;          // MKCKKS_ROW3X=1: three-round 8x8x4 fused kernels on 256-point rows
-    bool one_lane = false;       // MKCKKS_SUM_ONE_LANE=1: one client lane (kernels strictly serial)
-    bool conv_fp = true;         // MKCKKS_CONV_FP=0: conversion sources always as packed 30-bit halves
-    bool qsum = true;            // MKCKKS_QSUM=0: per-client key switch + k_row_tail_sum instead of the merged flow
     static Knobs from_env();
 };
 
@@ -169,7 +154,6 @@ private:
                     bool rows_int_only = false, uint32_t in_group = 0, size_t in_gstride = 0);
     bool qsum_ok(uint32_t nl) const;
     void reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uint32_t n_clients, uint32_t n_ct, uint32_t nl);
-    void reencrypt_sum_lanes(const u64 *cts, const u64 *evks, u64 *out, uint32_t n_clients, uint32_t n_ct, uint32_t nl);
     const u64 *p_doubles();
     // returns true when the inverse ROW pass of the P limbs was done on the fly into `pc` (ModDown then starts with
     // the inverse column pass)
@@ -197,8 +181,6 @@ private:
     hipEvent_t copy_ev_[COPY_RING] = {};
     hipEvent_t ev_fence_ = nullptr;
     uint64_t next_ticket_ = 1, done_ticket_ = 0;  // every ticket <= done_ticket_ is known complete
-    hipStream_t side_stream_ = nullptr;  // second client lane of reencrypt_sum
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     bool skip_rows_ = false;  // modup_core: leave the row pass of the converted digits to the fused kernels
     uint32_t *d_rot_ = nullptr;
     void *d_ksi_ = nullptr;

@@ -43,10 +43,7 @@ struct NttTables {
     const unsigned char *h_fp_of;  // HOST pointer (never read on the device): per limb id, 1 = fp64 instance
     uint32_t int_pm;  // HOST decision: the integer limbs run on the AR_PM instances (all of them qualify), else AR_INT
     unsigned long long *stamps;  // diagnostic builds (-DMK_STAMP=1) with MKCKKS_STAMPS=1: per-wave phase stamps; else null
-    uint32_t conv_lds;    // HOST: k_conv_lds for the ModUp conversions it covers
-    uint32_t conv_pair2;  // HOST: bit 0 / 1 = k_conv_col2 (two targets per workgroup) for the integer / fp64 class
     uint32_t cu_affine;  // 1: workgroups that share operand tiles are placed on the same CU (ntt_radix.hpp: group_member)
-    uint32_t stagger;  // start-phase stagger of a kernel's first generation of workgroups, percent of the built-in steps (0 = off)
 };
 // arithmetic of a radix-kernel instance (template parameter AR; AR_INT / AR_FP keep the values of the old bool)
 constexpr int AR_INT = 0, AR_FP = 1, AR_PM = 2;

@@ -16,12 +16,13 @@
 // q = 2^k - c, reduction by folding at bit k; what OpenFHE's 60-bit primes allow) or Shoup/Harvey lazy butterflies
 // (AR_INT, any modulus); the host launches the fp64 and the integer instance over the limbs of their class, and picks
 // ONE integer arithmetic per context (NttTables::int_pm: every integer limb qualifies for AR_PM).  512-point rows (N = 2^17) use three rounds of
-// radix 8 (k_ntt_row3).  Fused kernels: k_conv_col (approximate base conversion + forward column pass),
-// k_row_inner_fp (forward row pass of the converted digits + eval-key inner product, fp64 limbs), k_row_tail_sum /
-// k_row_tail_sum2 (forward row pass + ModDown tail + sum over clients), and their three-round counterparts
-// k_row3_inner_fp / k_row3_tail_sum for 512-point (and optionally 256-point) rows.  In every row kernel a wavefront
-// owns complete rows, so LDS hand-offs are wave-level (wave_lds_sync) and the kernels contain no workgroup barrier
-// after the twiddle staging.
+// radix 8 (k_ntt_row3).  Fused kernels: k_conv_col (approximate base conversion + forward column pass), k_icol_sum +
+// k_conv_col_psum (ApproxModDown's conversion for a whole group of clients), k_switch_col (rescale), k_row_inner_fp /
+// k_row3_inner_fp (forward row pass of the converted digits + eval-key inner product, fp64 limbs; single re-encryptions),
+// k_row3_inner_int (the same for the integer limbs, continuing into the inverse row pass on the P limbs),
+// k_row3_tail_once and, in qsum_kernels.hpp, k_qsum3_fp (the Q-limb half of the n-client step).  In every row kernel a
+// wavefront owns complete rows, so LDS hand-offs are wave-level (wave_lds_sync) and the kernels contain no workgroup
+// barrier after the twiddle staging.
 #pragma once
 #include "modarith.hpp"
 #include "ntt_kernels.hpp"
@@ -130,21 +131,6 @@ struct Stamper {
         }
     }
 };
-
-// Start-phase stagger.  Every workgroup of a pass does the same amount of work, so the W workgroups that start together
-// on a CU stay in step for the whole launch: they wait for their loads at the same time (the SIMDs idle) and compete for
-// the VALU at the same time.  Delaying the FIRST generation's workgroups by 0 .. W-1 W-ths of a workgroup's lifetime puts
-// the residents of a CU into different phases, and every later workgroup inherits the phase of the one whose slot it
-// takes.  Workgroup b of the first generation lands on CU (b / 8) % 32 of XCD b % 8 (tools/probe_dispatch.hip), so
-// (b >> 8) % W enumerates the residents of a CU.  STEP: one W-th of the lifetime in s_sleep(16) units (1024 cycles).
-template <int W, int STEP>
-MK_D void stagger_start(uint32_t pct) {
-    if (!pct) return;
-    const uint32_t b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (b >= 256u * W) return;
-    const uint32_t n = ((b >> 8) % W) * (uint32_t)STEP * pct / 100u;
-    for (uint32_t i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
-}
 
 // 1-D grids over (group, member): the members of a group share operand tiles (the source tiles of a conversion, the
 // twiddle / eval-key tiles of a row tile).  Workgroup b runs on XCD b % 8 (round-robin dispatch), so with 8 | groups a
@@ -614,7 +600,6 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_col_r(NttIo io, NttTable
     constexpr int H = TL::H, S = TL::S;
     __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
     const uint32_t poly = blockIdx.y / io.nsel, sl = nth_set_bit(io.slot_mask, blockIdx.y % io.nsel);
-    stagger_start<4, 8>(T.stagger);
     if (ntt_slot_skipped(io, poly, io.vslot0 + sl)) return;  // block-uniform
     const uint32_t id = limb_id_of(io.vslot0 + sl, io.nl, T.L);
     const LimbConst lc = T.limb[id];
@@ -683,7 +668,6 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_ntt_col_r(NttIo io, NttTable
 // inverse transform already multiplied by [(S/s_i)^-1]_{s_i} (folded into its N^-1 scaling).
 // Grid: 1-D, (item, target limb, column tile); the n_out workgroups that share one source tile are made
 // neighbours inside one XCD's queue so the 4 source tiles are fetched from HBM once and then hit in L2.
-constexpr int MAX_CONV_TARGETS = 40;  // = MAX_CONV_OUT (engine.hpp)
 struct ConvIo {
     const u64 *in;      // [items][in_slots][N]
     u64 *out;           // [items][out_slots][N]
@@ -707,12 +691,6 @@ struct ConvIo {
 #define MK_PROBE_SRC(src, limb_off, row_off) ((u64)threadIdx.x * 0x9E3779B97F4A7C15ull + (limb_off) + (row_off))
 #else
 #define MK_PROBE_SRC(src, limb_off, row_off) (src)[(limb_off) + (row_off)]
-#endif
-#ifndef MK_CL_STORE
-#define MK_CL_STORE 0
-#endif
-#ifndef MK_CONV2_DEPTH
-#define MK_CONV2_DEPTH 4  // the same ring in the two-target kernel k_conv_col2
 #endif
 
 // canonical integer below 2^52 held in a double -> its 30-bit halves (what split30 gives for the u64)
@@ -795,7 +773,6 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTable
     constexpr int H = TL::H, S = TL::S;
     static_assert(SRCMODE == 0 || N_IN <= 4, "double sources: at most 4 per digit");
     __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
-    stagger_start<4, (AR == AR_FP ? 10 : 14)>(T.stagger);
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
     const uint32_t groups = io.items * tiles;  // source tiles
     uint32_t grp, jt;
@@ -867,171 +844,6 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTable
     else stm.flush<1>(T.stamps, true);
 }
 
-// k_conv_col for TWO targets of one arithmetic class per workgroup (at most 4 sources).  Every target limb's workgroup
-// pulls the same 4 source tiles (128 KiB) through its CU's L1 to produce 32 KiB, and that pull -- not the arithmetic, not
-// the number of loads in flight -- is what the conversion phase waits for (in-kernel stamps: 24 000 of a wave's 32 000
-// cycles; 16 bytes per clock and CU).  Two conversions from one pass over the sources halve it; the second target's 16
-// words wait in registers while the first goes through its column pass (3 waves per SIMD instead of 4).  The last group
-// of an odd target count carries one live target.
-template <int LOG_H, int N_IN, int AR, typename CONV, int SRCMODE = 0>
-__global__ __launch_bounds__(NTT_THREADS, 3) void k_conv_col2(ConvIo io, NttTables T, CONV cv) {
-    using TL = ColTile<LOG_H>;
-    constexpr int H = TL::H, S = TL::S;
-    static_assert(N_IN <= 4, "target pairs: at most 4 sources");
-    __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
-    const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
-    const uint32_t groups = io.items * tiles, ntg = (io.nsel + 1) / 2;
-    uint32_t grp, jg;
-    group_member(blockIdx.x, groups, ntg, T.cu_affine, grp, jg);
-    const bool two = jg * 2 + 1 < io.nsel;  // workgroup-uniform
-    const uint32_t jta = nth_set_bit(io.target_mask, jg * 2), jtb = two ? nth_set_bit(io.target_mask, jg * 2 + 1) : jta;
-    uint32_t item, tile;
-    conv_item_tile(grp, groups, io.items, tiles, item, tile);
-    const uint32_t ida = cv.dst_id[jta], idb = cv.dst_id[jtb];
-    const LimbConst la = T.limb[ida], lb = T.limb[idb];
-    if ((la.fp != 0) != (AR == AR_FP) || (lb.fp != 0) != (AR == AR_FP)) return;  // never: the host pairs targets of one class
-    const int c = threadIdx.x % S, j = threadIdx.x / S;
-    const u64 *src = io.in + (size_t)item * io.in_stride + tile * S + c;
-    ConvConst<N_IN> ka, kb;
-    conv_consts<N_IN, AR, SRCMODE>(cv, jta, ka);
-    conv_consts<N_IN, AR, SRCMODE>(cv, jtb, kb);
-    constexpr int DEPTH = MK_CONV2_DEPTH < H ? MK_CONV2_DEPTH : H;
-    u64 ring[DEPTH][N_IN], xa[H], xb[H];
-#pragma unroll
-    for (int k = 0; k < DEPTH; ++k)
-#pragma unroll
-        for (int i = 0; i < N_IN; ++i) ring[k][i] = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2];
-#pragma unroll
-    for (int k = 0; k < H; ++k) {
-        u64 p[N_IN];
-#pragma unroll
-        for (int i = 0; i < N_IN; ++i) p[i] = ring[k % DEPTH][i];
-        if (k + DEPTH < H) {
-#pragma unroll
-            for (int i = 0; i < N_IN; ++i)
-                ring[k % DEPTH][i] = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * (k + DEPTH)) * r2];
-        }
-        uint32_t a0[N_IN], a1[N_IN];
-        if (!((AR == AR_FP) && SRCMODE != 0)) conv_split_sources<N_IN, SRCMODE>(p, a0, a1);  // once for both targets
-        xa[k] = conv_output<N_IN, AR, SRCMODE>(p, a0, a1, ka, la);
-        xb[k] = conv_output<N_IN, AR, SRCMODE>(p, a0, a1, kb, lb);
-    }
-    u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jta] * n + tile * S + c;
-    col_forward_finish<LOG_H, AR>(xa, lds, T.tw + (size_t)ida * n, T.tw_sh + (size_t)ida * n, la, j, c, dst, r2);
-    if (!two) return;
-    __syncthreads();  // the first target's exchange is read out
-    dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jtb] * n + tile * S + c;
-    // the second pass's twiddle loads must not be hoisted above the first pass (60 more live registers): its table
-    // pointers are opaque until here
-    const u64 *twb = T.tw + (size_t)idb * n, *twb_sh = T.tw_sh + (size_t)idb * n;
-    asm volatile("" : "+s"(twb), "+s"(twb_sh));
-    col_forward_finish<LOG_H, AR>(xb, lds, twb, twb_sh, lb, j, c, dst, r2);
-}
-
-// ---- ModUp conversion with the sources in LDS (round 3) ---------------------------------------------------------------
-// k_conv_col gives every target limb of a source tile its own workgroup: 12 workgroups pull the same 4 source tiles
-// (128 KiB) through their CUs' L1 to produce 32 KiB each -- 9.4 GB per step through L2 -- and the in-kernel stamps
-// (profiles/r03_stamps_*) show what that costs: a wave spends 20 000 of its 31 000 cycles in the conversion loop, 4 000 when
-// the same loads hit in L1 (timing probe), for 1 200 cycles of arithmetic; more loads in flight, 16-byte loads and L1
-// sharing between the co-resident workgroups move it by 1-5 %: a CU's L1 fills from L2 at ~16 bytes per clock here and that
-// is the bound.  This kernel reads a source tile ONCE: a workgroup stages the N_IN source limbs of a 4-column tile
-// (256 rows x 32 bytes each) in LDS and its four waves then work through ALL targets of the digit, one (target limb)
-// task at a time per wave -- conversion out of LDS, both rounds of the forward column pass, store.  A wave's 64 lanes are
-// 16 row groups x 4 columns, so the exchange between the rounds stays inside the wave (wave-private LDS tile,
-// wave_lds_sync): after the fill there is no workgroup barrier, waves take tasks from an LDS counter (integer-class
-// targets first: they take longest), and the arithmetic class of a task is a wave-uniform branch.  66 KiB of LDS for 4
-// sources: 2 workgroups per CU.  The 32-byte row segments of neighbouring tiles meet in L2: conv_item_tile makes the
-// tiles of an item consecutive in one XCD's queue.
-constexpr int CL_COLS = 4, CL_BLK = 16 * CL_COLS + 4, CL_TILE = 16 * CL_BLK;  // wave tile: 16 blocks of 16 rows x 4 columns, padded
-struct ConvTargets {
-    uint8_t idx[MAX_CONV_TARGETS];  // indices into cv.dst_*, in the order the tasks are handed out
-    uint32_t n;
-};
-MK_D int cl_at(int blk, int kk, int c) { return blk * CL_BLK + kk * CL_COLS + c; }
-// forward column pass of one wave's 4 columns (see col_forward_finish): rows j + 16 k in x[] on entry
-template <int AR>
-MK_D void col_forward_finish_wave(u64 (&x)[16], u64 *tile, const u64 *tw, const u64 *tw_sh, const LimbConst &lc, int j, int c,
-                                  u64 *dst_col, uint32_t r2) {
-    constexpr int H = 16;
-    u64 w[H - 1], wp[H - 1], w2[H - 1], wp2[H - 1];
-    load_round_twiddles<4>(tw, tw_sh, 1u, w, wp);
-    radix_forward_any<4, AR>(x, w, wp, lc);
-    load_round_twiddles<4>(tw, tw_sh, (uint32_t)(H + j), w2, wp2);
-#pragma unroll
-    for (int k = 0; k < H; ++k) tile[cl_at(k, j, c)] = x[k];  // row j + H k
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < H; ++k) x[k] = tile[cl_at(j, k, c)];  // row H j + k
-    radix_forward_any<4, AR>(x, w2, wp2, lc);
-#if MK_CL_STORE == 0  // 32-byte row segments: plain stores, so that the pieces of a 128-byte line meet in L2
-#pragma unroll
-    for (int k = 0; k < H; ++k) dst_col[(size_t)(H * j + k) * r2] = x[k];
-#elif MK_CL_STORE == 1
-#pragma unroll
-    for (int k = 0; k < H; ++k) st_pass(dst_col + (size_t)(H * j + k) * r2, x[k]);
-#else  // timing probe: one store per thread
-    u64 acc = 0;
-#pragma unroll
-    for (int k = 0; k < H; ++k) acc ^= x[k];
-    dst_col[(size_t)(H * j) * r2] = acc;
-#endif
-    wave_lds_sync();  // the tile is read out before the next task writes it
-}
-template <int N_IN, int AR, int SRCMODE, typename CONV>
-MK_D void conv_lds_task(const u64 *srcs, u64 *tile, const CONV &cv, uint32_t jt, const LimbConst &lc, const NttTables &T, int j, int c,
-                        u64 *dst_col, uint32_t r2) {
-    ConvConst<N_IN> kc;
-    conv_consts<N_IN, AR, SRCMODE>(cv, jt, kc);
-    u64 x[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        u64 p[N_IN];
-#pragma unroll
-        for (int i = 0; i < N_IN; ++i) p[i] = srcs[i * (256 * CL_COLS) + (j + 16 * k) * CL_COLS + c];
-        uint32_t a0[N_IN], a1[N_IN];
-        if (!((AR == AR_FP) && SRCMODE != 0)) conv_split_sources<N_IN, SRCMODE>(p, a0, a1);
-        x[k] = conv_output<N_IN, AR, SRCMODE>(p, a0, a1, kc, lc);
-        asm volatile("" : "+v"(x[k]));
-    }
-    const uint32_t n = 1u << T.log_n, id = cv.dst_id[jt];
-    col_forward_finish_wave<AR>(x, tile, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst_col, r2);
-}
-template <int N_IN, int ARI, typename CONV, int SRCMODE>
-__global__ __launch_bounds__(NTT_THREADS, 2) void k_conv_lds(ConvIo io, NttTables T, CONV cv, ConvTargets tg) {
-    static_assert(N_IN <= 4, "sources of one digit in LDS: at most 4");
-    __shared__ u64 srcs[N_IN * 256 * CL_COLS];
-    __shared__ u64 tiles_[(NTT_THREADS / 64) * CL_TILE];
-    __shared__ uint32_t next_task;
-    const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / CL_COLS;  // 256 rows (log_r1 == 8: host checks)
-    const uint32_t groups = io.items * tiles;
-    uint32_t item, tile;
-    conv_item_tile(blockIdx.x, groups, io.items, tiles, item, tile);
-    const u64 *in = io.in + (size_t)item * io.in_stride + tile * CL_COLS;
-    if (threadIdx.x == 0) next_task = 0;
-    // fill: 16-byte pieces, two per 32-byte row segment; piece p of the tile goes to LDS words 2p, 2p + 1
-#pragma unroll
-    for (int m = 0; m < 2 * N_IN; ++m) {
-        const uint32_t p = threadIdx.x + NTT_THREADS * m, i = m >> 1, row = (p & 511u) >> 1, q = p & 1u;
-        const ulong2 v = *reinterpret_cast<const ulong2 *>(in + (size_t)cv.src_slot[i] * n + (size_t)row * r2 + 2 * q);
-        *reinterpret_cast<ulong2 *>(srcs + 2 * p) = v;
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, j = lane >> 2, c = lane & 3;
-    u64 *tile_w = tiles_ + (threadIdx.x >> 6) * CL_TILE;
-    u64 *out = io.out + (size_t)item * io.out_stride + tile * CL_COLS + c;
-    for (;;) {
-        uint32_t task = 0;
-        if (lane == 0) task = atomicAdd(&next_task, 1u);
-        task = (uint32_t)__builtin_amdgcn_readfirstlane((int)task);
-        if (task >= tg.n) break;
-        const uint32_t jt = tg.idx[task];
-        const LimbConst lc = T.limb[cv.dst_id[jt]];
-        u64 *dst_col = out + (size_t)cv.dst_slot[jt] * n;
-        if (lc.fp) conv_lds_task<N_IN, AR_FP, SRCMODE>(srcs, tile_w, cv, jt, lc, T, j, c, dst_col, r2);
-        else conv_lds_task<N_IN, ARI, SRCMODE>(srcs, tile_w, cv, jt, lc, T, j, c, dst_col, r2);
-    }
-}
-
 // ---- ApproxModDown's conversion P -> Q_l for a whole group of clients at once ------------------------------------------
 // The reference converts every client's key-switch result on its own (ApproxModDown inside each ReEncrypt) and adds the
 // re-encryptions afterwards (EvalAdd).  With x_{c,k} the canonical residue mod p_k of client c's coefficient (the inverse
@@ -1057,7 +869,6 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_icol_sum(const u64 *pc, u64 
     constexpr int H = TL::H, S = TL::S;
     static_assert(AR != AR_FP, "P limbs are integer-class");
     __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
-    stagger_start<3, 40>(T.stagger);
     const uint32_t poly = blockIdx.y / K, k = blockIdx.y % K;
     const uint32_t id = T.L + k;
     const LimbConst lc = T.limb[id];
@@ -1110,7 +921,6 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_psum(ConvIo io, Ntt
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
     __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
-    stagger_start<4, 12>(T.stagger);
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
     const uint32_t groups = io.items * tiles;
     uint32_t grp, jt;
@@ -1208,7 +1018,6 @@ __global__ __launch_bounds__(NTT_THREADS) void k_switch_col(const u64 *last, u64
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
     __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
-    stagger_start<4, 8>(T.stagger);
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2;
     const uint32_t sl = nth_set_bit(target_mask, blockIdx.y), item = blockIdx.z;  // remaining Q limb: slot == limb id
     const LimbConst lc = T.limb[sl];
@@ -1240,64 +1049,6 @@ struct TailArgs {
     uint32_t accumulate; // out += result (running aggregate over clients) instead of out = result
 };
 
-// ---- wavefront-shuffle exchange (experiment, -DMK_ROW_SHUFFLE=1) ---------------------------------------------------
-// The hand-off between the two rounds of a 256-point row is a 16 x 16 transpose between the lane index j (16 lanes own a
-// row) and the register index k.  Instead of the wave-private LDS tile it can be done in registers with four butterfly
-// steps over the lane bits 8, 4, 2, 1: in step b the element (lane j, register k) with bit b of j != bit b of k trades
-// places with (j ^ b, k ^ b).  Lane distances 8 and 4 are DPP row shifts whose bank mask (groups of 4 lanes) picks the
-// receiving half directly: 2 v_mov_b32_dpp per 64-bit word.  Distances 2 and 1 stay inside a quad (quad_perm), where the
-// bank mask cannot tell the lanes apart: select what to send, move, select where it lands -- 4 instructions per 32 bits.
-// 192 VALU instructions per thread replace 16 ds_write_b64 + 8 ds_read2_b64 (measurement: DESIGN.md section 4).
-#ifndef MK_ROW_SHUFFLE
-#define MK_ROW_SHUFFLE 0
-#endif
-template <int CTRL, int BANKS>
-MK_D u64 dpp_word(u64 keep, u64 from) {  // lanes of the banks in BANKS: `from` read at the lane CTRL points to; others: keep
-    const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)keep, (int)(uint32_t)from, CTRL, 0xf, BANKS, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(keep >> 32), (int)(uint32_t)(from >> 32), CTRL, 0xf, BANKS, false);
-    return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-template <int CTRL>
-MK_D u64 dpp_quad(u64 v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
-    return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-// x[k] of lane j (j = lane % 16)  <->  x[j] of lane k, inside every group of 16 lanes
-MK_D void transpose16_shuffle(u64 (&x)[16], int j) {
-    constexpr int ROW_SHL = 0x100, ROW_SHR = 0x110;  // DPP controls row_shl:n = 0x100 + n, row_shr:n = 0x110 + n
-#pragma unroll
-    for (int k0 = 0; k0 < 8; ++k0) {  // lane bit 8: lanes 0-7 (banks 0, 1) take register k0 of lane + 8 into k0 + 8, lanes 8-15 the reverse
-        const u64 a = x[k0], b = x[k0 + 8];
-        x[k0 + 8] = dpp_word<ROW_SHL + 8, 0x3>(b, a);
-        x[k0] = dpp_word<ROW_SHR + 8, 0xc>(a, b);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {  // lane bit 4: banks 0, 2 against banks 1, 3
-        const int k0 = (i & 3) | ((i & 4) << 1);
-        const u64 a = x[k0], b = x[k0 + 4];
-        x[k0 + 4] = dpp_word<ROW_SHL + 4, 0x5>(b, a);
-        x[k0] = dpp_word<ROW_SHR + 4, 0xa>(a, b);
-    }
-    const bool b2 = (j & 2) != 0, b1 = (j & 1) != 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {  // lane bit 2: partner = lane ^ 2, quad_perm [2, 3, 0, 1]
-        const int k0 = (i & 1) | ((i & 6) << 1);
-        const u64 a = x[k0], b = x[k0 + 2];
-        const u64 got = dpp_quad<0x4E>(b2 ? a : b);
-        x[k0] = b2 ? got : a;
-        x[k0 + 2] = b2 ? b : got;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {  // lane bit 1: partner = lane ^ 1, quad_perm [1, 0, 3, 2]
-        const int k0 = i << 1;
-        const u64 a = x[k0], b = x[k0 + 1];
-        const u64 got = dpp_quad<0xB1>(b1 ? a : b);
-        x[k0] = b1 ? got : a;
-        x[k0 + 1] = b1 ? b : got;
-    }
-}
-
 // Row pass over rows of R2 = H*H contiguous words: one workgroup = S consecutive rows (S*R2 contiguous
 // words).  The side that needs per-thread contiguous runs goes through LDS with coalesced 16-B accesses.
 template <int LOG_H, bool INV, int AR>
@@ -1307,7 +1058,6 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
     constexpr int H = TL::H, S = TL::S, R = TL::R, PAIRS = S * R / 2 / NTT_THREADS;
     __shared__ u64 lds[TL::WORDS + 2 * TA::WORDS];
     u64 *twa = lds + TL::WORDS, *twa_sh = twa + TA::WORDS;
-    stagger_start<4, 8>(T.stagger);
     // 1-D grid over (limb slot, row tile, polynomial).  All polynomials of one (slot, tile) read the same
     // 2*S*R-word twiddle tile: they are made consecutive inside ONE XCD's queue (blocks b, b+8, ... share an
     // XCD under round-robin dispatch) so the tile is fetched over the fabric once and then hits in that L2.
@@ -1337,15 +1087,11 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
         radix_forward_any<LOG_H, AR>(x, w, wp, lc);
         u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
         load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
-        if constexpr (MK_ROW_SHUFFLE && LOG_H == 4) {
-            transpose16_shuffle(x, j);
-        } else {
 #pragma unroll
-            for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
-            wave_lds_sync();
+        for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
+        wave_lds_sync();
 #pragma unroll
-            for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
-        }
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
         radix_forward_any<LOG_H, AR>(x, w2, wp2, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k)  // canonical u64, own words only
@@ -1404,236 +1150,16 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_r(NttIo io, NttTables T
             for (int k = 0; k < H; ++k) x[k] = dbits((double)x[k]);
         }
         radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
-        if constexpr (MK_ROW_SHUFFLE && LOG_H == 4) {
-            transpose16_shuffle(x, j);
-        } else {
 #pragma unroll
-            for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = x[k];
-            wave_lds_sync();
+        for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = x[k];
+        wave_lds_sync();
 #pragma unroll
-            for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, j + H * k)];
-        }
+        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, j + H * k)];
         TA::fetch(twa, twa_sh, g, w, wp);
         radix_inverse_any<LOG_H, AR>(x, w, wp, lc);
 #pragma unroll
         for (int k = 0; k < H; ++k) st_pass(dst + (size_t)g * R + j + H * k, x[k]);  // lazy [0,2q) (doubles on an fp limb): the column pass scales
     }
-}
-
-// ModDown row pass + tail + aggregation over clients in ONE kernel: for a (ciphertext, component, limb, row tile)
-// the workgroup walks the n_clients converted polynomials, finishes each one's forward transform, applies the
-// ApproxModDown tail (ctilde_Q - conv) * P^-1 (+ c0 on component 0) and keeps the running coefficient-wise sum
-// in registers; the aggregate is written once instead of being read and re-written per client
-// (ReEncrypt x n_clients + EvalAdd x (n_clients - 1) of aggregateEncryptedWeights.cpp:82, one output stream).
-struct SumArgs {
-    const u64 *conv;     // [client][poly][nl][N]  column-passed converted limbs (lazy / doubles)
-    const u64 *til;      // [client][poly][ext][N] key-switch accumulators over Q_l P
-    const u64 *cts;      // [client][ct][2][nl][N] input ciphertexts (c0 added on component 0)
-    u64 *out;            // [poly][nl][N] = [ct][2][nl][N]
-    const u64 *pinv, *pinv_sh;
-    size_t conv_cstride, til_cstride, ct_cstride;  // words between clients
-    size_t ct_stride;    // words between ciphertexts of one client in `cts`
-    uint32_t n_clients, nl, ext, n_polys;
-    unsigned long long slot_mask;
-    uint32_t nsel;
-    uint32_t init_from_out;  // continue a running sum: the accumulators start from `out` instead of zero
-    uint32_t til_compact = 0;  // til holds only this launch's slots: [client][poly][nsel][N], slot index = rank in slot_mask
-};
-template <int LOG_H, int AR, int WAVES>
-__global__ __launch_bounds__(NTT_THREADS, WAVES) void k_row_tail_sum(SumArgs a, NttTables T) {
-    using TL = RowTile<LOG_H>;
-    using TA = RowTwA<LOG_H>;
-    constexpr int H = TL::H, S = TL::S, R = TL::R, PAIRS = S * R / 2 / NTT_THREADS;
-    __shared__ u64 lds[TL::WORDS + 2 * TA::WORDS];
-    u64 *twa = lds + TL::WORDS, *twa_sh = twa + TA::WORDS;
-    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
-    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
-    uint32_t grp, poly;
-    group_member(blockIdx.x, groups, a.n_polys, T.cu_affine, grp, poly);
-    const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);  // Q limb: slot == limb id
-    const LimbConst lc = T.limb[sl];
-    if ((lc.fp != 0) != (AR == AR_FP)) return;
-    const uint32_t row0 = (grp % tiles) * S;
-    const int g = threadIdx.x / H, j = threadIdx.x % H;
-    const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
-    const u64 *twb = T.twb + (size_t)sl * 2 * n;
-    const u64 pi = a.pinv[sl], pi_sh = a.pinv_sh[sl];
-    const size_t tile_off = (size_t)row0 * R;
-    stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);  // round-A twiddles are the same for every client
-    u64 *dst = a.out + ((size_t)poly * a.nl + sl) * n + tile_off;
-    ulong2 acc[PAIRS];
-#pragma unroll
-    for (int i = 0; i < PAIRS; ++i)
-        acc[i] = a.init_from_out ? reinterpret_cast<const ulong2 *>(dst)[wave_pair<LOG_H>(i)] : ulong2{0, 0};
-    // software pipeline over clients: the H input words of client c+1 are requested while client c's tail streams
-    // (x[] is dead by then), so their latency is off the critical path
-    const u64 *src0 = a.conv + ((size_t)poly * a.nl + sl) * n + tile_off + (size_t)g * R + j;
-    u64 x[H];
-#pragma unroll
-    for (int k = 0; k < H; ++k) x[k] = src0[H * k];
-    for (uint32_t c = 0; c < a.n_clients; ++c) {
-        u64 w[H - 1], wp[H - 1];
-        wave_lds_sync();  // twiddles staged (first client) / previous client's copy-out finished reading LDS
-        TA::fetch(twa, twa_sh, g, w, wp);
-        radix_forward_any<LOG_H, AR>(x, w, wp, lc);
-#pragma unroll
-        for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
-        wave_lds_sync();
-#pragma unroll
-        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
-        load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w, wp);
-        radix_forward_any<LOG_H, AR>(x, w, wp, lc);
-#pragma unroll
-        for (int k = 0; k < H; ++k)
-            lds[TL::at(g, H * j + k)] = (AR == AR_FP) ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
-        if (c + 1 < a.n_clients) {
-            const u64 *nxt = src0 + (size_t)(c + 1) * a.conv_cstride;
-#pragma unroll
-            for (int k = 0; k < H; ++k) x[k] = nxt[H * k];
-        }
-        wave_lds_sync();
-        const u64 *tq = a.til + (size_t)c * a.til_cstride + ((size_t)poly * a.ext + sl) * n + tile_off;
-        const u64 *c0 = (poly & 1) == 0
-                            ? a.cts + (size_t)c * a.ct_cstride + (size_t)(poly >> 1) * a.ct_stride + (size_t)sl * n + tile_off
-                            : nullptr;
-#pragma unroll
-        for (int i = 0; i < PAIRS; ++i) {
-            const int e = wave_pair<LOG_H>(i);
-            const int gg = (2 * e) / R, xx = (2 * e) % R;
-            const ulong2 t = reinterpret_cast<const ulong2 *>(tq)[e];
-            ulong2 v;
-            v.x = shoup_mul(sub_mod(t.x, lds[TL::at(gg, xx)], lc.q), pi, pi_sh, lc.q);
-            v.y = shoup_mul(sub_mod(t.y, lds[TL::at(gg, xx + 1)], lc.q), pi, pi_sh, lc.q);
-            if (c0) {
-                const ulong2 z = reinterpret_cast<const ulong2 *>(c0)[e];
-                v.x = add_mod(v.x, z.x, lc.q);
-                v.y = add_mod(v.y, z.y, lc.q);
-            }
-            acc[i].x = add_mod(acc[i].x, v.x, lc.q);
-            acc[i].y = add_mod(acc[i].y, v.y, lc.q);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[wave_pair<LOG_H>(i)] = acc[i];
-}
-
-// Same pass with TWO clients in flight per workgroup iteration: both clients' tiles go through the rounds together,
-// so every twiddle fetched (LDS broadcast in round A, per-thread global loads in round B) feeds two butterflies and
-// the two independent dependency chains cover each other's LDS / memory latency at 2 waves per SIMD.  An odd client
-// count runs its last iteration with the second slot masked (its loads alias the first slot's client).
-template <int LOG_H, int AR>
-__global__ __launch_bounds__(NTT_THREADS, 2) void k_row_tail_sum2(SumArgs a, NttTables T) {
-    using TL = RowTile<LOG_H>;
-    using TA = RowTwA<LOG_H>;
-    constexpr int H = TL::H, S = TL::S, R = TL::R, PAIRS = S * R / 2 / NTT_THREADS;
-    __shared__ u64 lds[2 * TL::WORDS + 2 * TA::WORDS];
-    u64 *ldsb = lds + TL::WORDS, *twa = lds + 2 * TL::WORDS, *twa_sh = twa + TA::WORDS;
-    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
-    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
-    uint32_t grp, poly;
-    group_member(blockIdx.x, groups, a.n_polys, T.cu_affine, grp, poly);
-    const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);  // Q limb: slot == limb id
-    const LimbConst lc = T.limb[sl];
-    if ((lc.fp != 0) != (AR == AR_FP)) return;
-    const uint32_t row0 = (grp % tiles) * S;
-    const int g = threadIdx.x / H, j = threadIdx.x % H;
-    const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
-    const u64 *twb = T.twb + (size_t)sl * 2 * n;
-    const u64 pi = a.pinv[sl], pi_sh = a.pinv_sh[sl];
-    const size_t tile_off = (size_t)row0 * R;
-    stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);
-    u64 *dst = a.out + ((size_t)poly * a.nl + sl) * n + tile_off;
-    ulong2 acc[PAIRS];
-#pragma unroll
-    for (int i = 0; i < PAIRS; ++i)
-        acc[i] = a.init_from_out ? reinterpret_cast<const ulong2 *>(dst)[wave_pair<LOG_H>(i)] : ulong2{0, 0};
-    const u64 *src0 = a.conv + ((size_t)poly * a.nl + sl) * n + tile_off + (size_t)g * R + j;
-    const size_t til_off = ((size_t)poly * a.ext + (a.til_compact ? grp / tiles : sl)) * n + tile_off;
-    const size_t ct_off = (size_t)(poly >> 1) * a.ct_stride + (size_t)sl * n + tile_off;
-    const bool with_c0 = (poly & 1) == 0;
-    u64 xa[H], xb[H];
-    {
-        const u64 *pb = src0 + (size_t)(a.n_clients > 1 ? 1 : 0) * a.conv_cstride;
-#pragma unroll
-        for (int k = 0; k < H; ++k) xa[k] = ld_stream(src0 + H * k);
-#pragma unroll
-        for (int k = 0; k < H; ++k) xb[k] = ld_stream(pb + H * k);
-    }
-    for (uint32_t c = 0; c < a.n_clients; c += 2) {
-        const bool has_b = c + 1 < a.n_clients;  // workgroup-uniform
-        const uint32_t cb = has_b ? c + 1 : c;
-        {
-            u64 w[H - 1], wp[H - 1];
-            wave_lds_sync();  // twiddles staged (first pair) / previous pair's tail finished reading LDS
-            TA::fetch(twa, twa_sh, g, w, wp);
-            radix_forward_any<LOG_H, AR>(xa, w, wp, lc);
-            radix_forward_any<LOG_H, AR>(xb, w, wp, lc);
-        }
-        u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
-        load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
-#pragma unroll
-        for (int k = 0; k < H; ++k) {
-            lds[TL::at(g, j + H * k)] = xa[k];
-            ldsb[TL::at(g, j + H * k)] = xb[k];
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int k = 0; k < H; ++k) {
-            xa[k] = lds[TL::at(g, H * j + k)];
-            xb[k] = ldsb[TL::at(g, H * j + k)];
-        }
-        radix_forward_any<LOG_H, AR>(xa, w2, wp2, lc);
-        radix_forward_any<LOG_H, AR>(xb, w2, wp2, lc);
-#pragma unroll
-        for (int k = 0; k < H; ++k) {
-            lds[TL::at(g, H * j + k)] = (AR == AR_FP) ? fp_to_canonical(bitsd(xa[k]), lc.qd, lc.qinv) : canon8(xa[k], lc.q, lc.q2);
-            ldsb[TL::at(g, H * j + k)] = (AR == AR_FP) ? fp_to_canonical(bitsd(xb[k]), lc.qd, lc.qinv) : canon8(xb[k], lc.q, lc.q2);
-        }
-        if (c + 2 < a.n_clients) {  // next pair's inputs are requested while this pair's tail streams
-            const u64 *na = src0 + (size_t)(c + 2) * a.conv_cstride;
-            const u64 *nb = src0 + (size_t)(c + 3 < a.n_clients ? c + 3 : c + 2) * a.conv_cstride;
-#pragma unroll
-            for (int k = 0; k < H; ++k) xa[k] = ld_stream(na + H * k);
-#pragma unroll
-            for (int k = 0; k < H; ++k) xb[k] = ld_stream(nb + H * k);
-        }
-        wave_lds_sync();
-        const u64 *tqa = a.til + (size_t)c * a.til_cstride + til_off;
-        const u64 *tqb = a.til + (size_t)cb * a.til_cstride + til_off;
-        const u64 *c0a = a.cts + (size_t)c * a.ct_cstride + ct_off;
-        const u64 *c0b = a.cts + (size_t)cb * a.ct_cstride + ct_off;
-#pragma unroll
-        for (int i = 0; i < PAIRS; ++i) {
-            const int e = wave_pair<LOG_H>(i);
-            const int gg = (2 * e) / R, xx = (2 * e) % R;
-            const ulong2 ta = ld_stream2(reinterpret_cast<const ulong2 *>(tqa) + e);
-            const ulong2 tb = ld_stream2(reinterpret_cast<const ulong2 *>(tqb) + e);
-            ulong2 va, vb;
-            va.x = shoup_mul(sub_mod(ta.x, lds[TL::at(gg, xx)], lc.q), pi, pi_sh, lc.q);
-            va.y = shoup_mul(sub_mod(ta.y, lds[TL::at(gg, xx + 1)], lc.q), pi, pi_sh, lc.q);
-            vb.x = shoup_mul(sub_mod(tb.x, ldsb[TL::at(gg, xx)], lc.q), pi, pi_sh, lc.q);
-            vb.y = shoup_mul(sub_mod(tb.y, ldsb[TL::at(gg, xx + 1)], lc.q), pi, pi_sh, lc.q);
-            if (with_c0) {
-                const ulong2 za = ld_stream2(reinterpret_cast<const ulong2 *>(c0a) + e);
-                const ulong2 zb = ld_stream2(reinterpret_cast<const ulong2 *>(c0b) + e);
-                va.x = add_mod(va.x, za.x, lc.q);
-                va.y = add_mod(va.y, za.y, lc.q);
-                vb.x = add_mod(vb.x, zb.x, lc.q);
-                vb.y = add_mod(vb.y, zb.y, lc.q);
-            }
-            acc[i].x = add_mod(acc[i].x, va.x, lc.q);
-            acc[i].y = add_mod(acc[i].y, va.y, lc.q);
-            if (has_b) {
-                acc[i].x = add_mod(acc[i].x, vb.x, lc.q);
-                acc[i].y = add_mod(acc[i].y, vb.y, lc.q);
-            }
-            // keep the loads of the second half of the tile behind the first half's arithmetic: hoisting all
-            // 4*PAIRS 16-byte loads at once overflows the register file (the next pair's inputs are in flight too)
-            if (i == PAIRS / 2 - 1) __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[wave_pair<LOG_H>(i)] = acc[i];
 }
 
 // ModUp row pass + inner product with the eval key in ONE kernel, fp64 limbs only (EvalKeySwitchPrecomputeCore's
@@ -1931,7 +1457,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row3(NttIo io, NttTables T,
     }
 }
 
-// ---- fused kernels on 512-point rows (N = 2^17): the same fusions as k_row_tail_sum / k_row_inner_fp ----------
+// ---- fused kernels on the three-round row geometry (512-point rows of N = 2^17, 256-point rows as 8 x 8 x 4) ----------
 // A wavefront owns ONE row (64 threads x 8 words) in every phase, so after the cooperative twiddle staging all LDS
 // hand-offs are wave-level.  8 words per thread keep the accumulators small (16-32 registers): these kernels run at
 // high occupancy.
@@ -2059,82 +1585,6 @@ MK_D void row3_forward(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc_in)[7], con
 template <int LOGC>
 MK_D int row3_pair(int g, int t, int i) { return g * (RowT<LOGC>::R / 2) + t + RowT<LOGC>::TPR * i; }
 
-// ModDown row pass + tail + sum over clients (see k_row_tail_sum) on 512-point rows
-template <int AR, int LOGC>
-__global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_sum(SumArgs a, NttTables T) {
-    using TL = RowT<LOGC>;
-    constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
-    __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
-    Row3Ctx c;
-    c.lds = lds;
-    c.twa = lds + TL::WORDS;
-    c.twa_sh = c.twa + TL::TWA;
-    c.twb = c.twa_sh + TL::TWA;
-    c.twb_sh = c.twb + TL::TWB;
-    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
-    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
-    uint32_t grp, poly;
-    group_member(blockIdx.x, groups, a.n_polys, T.cu_affine, grp, poly);
-    const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);
-    const LimbConst lc = T.limb[sl];
-    if ((lc.fp != 0) != (AR == AR_FP)) return;
-    const uint32_t row0 = (grp % tiles) * S;
-    c.g = threadIdx.x / TPR;
-    c.t = threadIdx.x % TPR;
-    const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
-    row3_stage_twiddles<LOGC>(c, tw, tw_sh, r1 + row0);
-    u64 wc[7], wpc[7];
-    row3_load_c_twiddles<LOGC>(tw, tw_sh, r1 + row0 + c.g, c.t, wc, wpc);
-    const u64 pi = a.pinv[sl], pi_sh = a.pinv_sh[sl];
-    const size_t tile_off = (size_t)row0 * R;
-    u64 *dst = a.out + ((size_t)poly * a.nl + sl) * n + tile_off;
-    ulong2 acc[PAIRS];
-#pragma unroll
-    for (int i = 0; i < PAIRS; ++i)
-        acc[i] = a.init_from_out ? reinterpret_cast<const ulong2 *>(dst)[row3_pair<LOGC>(c.g, c.t, i)] : ulong2{0, 0};
-    const u64 *src0 = a.conv + ((size_t)poly * a.nl + sl) * n + tile_off + (size_t)c.g * R + c.t;
-    u64 x[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = ld_stream(src0 + TPR * k);
-    __syncthreads();  // twiddles staged
-    for (uint32_t cl = 0; cl < a.n_clients; ++cl) {
-        wave_lds_sync();  // previous client's tail finished reading this wave's row
-        row3_forward<AR, LOGC>(x, c, wc, wpc, lc);
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            lds[TL::at(c.g, 8 * c.t + k)] = (AR == AR_FP) ? fp_to_canonical(bitsd(x[k]), lc.qd, lc.qinv) : canon8(x[k], lc.q, lc.q2);
-        if (cl + 1 < a.n_clients) {
-            const u64 *nxt = src0 + (size_t)(cl + 1) * a.conv_cstride;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = ld_stream(nxt + TPR * k);
-        }
-        wave_lds_sync();
-        const u64 *tq = a.til + (size_t)cl * a.til_cstride +
-                        ((size_t)poly * a.ext + (a.til_compact ? grp / tiles : sl)) * n + tile_off;
-        const u64 *c0 = (poly & 1) == 0
-                            ? a.cts + (size_t)cl * a.ct_cstride + (size_t)(poly >> 1) * a.ct_stride + (size_t)sl * n + tile_off
-                            : nullptr;
-#pragma unroll
-        for (int i = 0; i < PAIRS; ++i) {
-            const int e = row3_pair<LOGC>(c.g, c.t, i);
-            const int xx = (2 * e) % R;
-            const ulong2 tt = ld_stream2(reinterpret_cast<const ulong2 *>(tq) + e);
-            ulong2 v;
-            v.x = shoup_mul(sub_mod(tt.x, lds[TL::at(c.g, xx)], lc.q), pi, pi_sh, lc.q);
-            v.y = shoup_mul(sub_mod(tt.y, lds[TL::at(c.g, xx + 1)], lc.q), pi, pi_sh, lc.q);
-            if (c0) {
-                const ulong2 z = ld_stream2(reinterpret_cast<const ulong2 *>(c0) + e);
-                v.x = add_mod(v.x, z.x, lc.q);
-                v.y = add_mod(v.y, z.y, lc.q);
-            }
-            acc[i].x = add_mod(acc[i].x, v.x, lc.q);
-            acc[i].y = add_mod(acc[i].y, v.y, lc.q);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < PAIRS; ++i) reinterpret_cast<ulong2 *>(dst)[row3_pair<LOGC>(c.g, c.t, i)] = acc[i];
-}
-
 // ModUp row pass + eval-key inner product on the fp64 Q limbs (see k_row_inner_fp) on 512-point rows
 template <int NPARTS, int LOGC>
 __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, NttTables T) {
@@ -2255,7 +1705,6 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_tail_once(TailOnceArgs 
     using TL = RowT<LOGC>;
     constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
     __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
-    stagger_start<3, 10>(T.stagger);
     Row3Ctx c;
     c.lds = lds;
     c.twa = lds + TL::WORDS;
@@ -2399,7 +1848,6 @@ __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_
     using TL = RowT<LOGC>;
     constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
     __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
-    stagger_start<(INVP ? MK_INVP_WAVES : 3), (INVP ? 27 : 14)>(T.stagger);
     Row3Ctx c;
     c.lds = lds;
     c.twa = lds + TL::WORDS;

@@ -12,7 +12,7 @@
 // aggregateEncryptedWeights.cpp:82).  Everything between the products and the final canonical value is ring arithmetic
 // mod q_t, so the stored residues are those of the reference's per-client chain, bit for bit.
 //
-// Against k_row_inner_fp + k_row_tail_sum2 this removes the round trip of the key-switch accumulators over Q through
+// Against a per-client fused row pass + inner product followed by a tail + sum kernel (rounds 1-2) this removes the round trip of the key-switch accumulators over Q through
 // HBM (2 L limb writes + 2 L limb reads per client ciphertext) and n - 1 of the n multiplications by P^-1.
 #pragma once
 #include "ntt_radix.hpp"
@@ -37,179 +37,10 @@ struct QSumArgs {
     uint32_t init_from_out;  // continue a running sum held in `out` (client groups)
 };
 
-template <int LOG_H, int NPARTS>
-__global__ __launch_bounds__(NTT_THREADS, 2) void k_qsum_fp(QSumArgs a, NttTables T) {
-    using TL = RowTile<LOG_H>;
-    using TA = RowTwA<LOG_H>;
-    constexpr int H = TL::H, S = TL::S, R = TL::R, PAIRS = S * R / 2 / NTT_THREADS;
-    constexpr int ND = NPARTS - 1;  // converted digits of a Q limb (every Q limb has an owning digit)
-    __shared__ u64 lds[TL::WORDS + 2 * TA::WORDS];
-    u64 *twa = lds + TL::WORDS, *twa_sh = twa + TA::WORDS;
-    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
-    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
-    uint32_t grp, b;
-    group_member(blockIdx.x, groups, a.cnt, T.cu_affine, grp, b);
-    const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);  // Q limb: slot == limb id
-    const LimbConst lc = T.limb[sl];
-    const int own = (int)(sl / a.alpha);
-    const uint32_t row0 = (grp % tiles) * S;
-    const int g = threadIdx.x / H, j = threadIdx.x % H;
-    const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
-    const u64 *twb = T.twb + (size_t)sl * 2 * n;
-    const size_t tile_off = (size_t)row0 * R;
-    const double q = lc.qd, qinv = lc.qinv;
-    const double pm = bitsd(a.pq[4 * sl]), pmq = bitsd(a.pq[4 * sl + 1]);
-    stage_twiddles_wave<LOG_H>(twa, twa_sh, tw, tw_sh, r1 + row0);  // round-A twiddles: the same for every transform
-    u64 *o0 = a.out + (size_t)b * a.out_stride + (size_t)sl * n + tile_off;
-    u64 *o1 = o0 + (size_t)a.nl * n;
-    double2 acc0[PAIRS], acc1[PAIRS];
-#pragma unroll
-    for (int i = 0; i < PAIRS; ++i) {
-        if (a.init_from_out) {  // the stored sum carries the factor P^-1: put P back (exact, mod q)
-            const int e = wave_pair<LOG_H>(i);
-            const ulong2 v0 = reinterpret_cast<const ulong2 *>(o0)[e], v1 = reinterpret_cast<const ulong2 *>(o1)[e];
-            acc0[i].x = fp_mulmod(u52_to_double(v0.x), pm, pmq, q);
-            acc0[i].y = fp_mulmod(u52_to_double(v0.y), pm, pmq, q);
-            acc1[i].x = fp_mulmod(u52_to_double(v1.x), pm, pmq, q);
-            acc1[i].y = fp_mulmod(u52_to_double(v1.y), pm, pmq, q);
-        } else {
-            acc0[i] = double2{0.0, 0.0};
-            acc1[i] = double2{0.0, 0.0};
-        }
-    }
-    // transform u of client c: u < ND converted digits (owning digit skipped); after the last client the two summed
-    // ModDown conversions (client index n_clients, u = 0, 1)
-    const size_t th_off = tile_off + (size_t)g * R + j;
-    auto src_of = [&](uint32_t c, int u) -> const u64 * {
-        if (c < a.n_clients && ND > 0) {
-            const size_t item = (size_t)c * a.cnt + b;
-            const int dj = u < own ? u : u + 1;
-            return a.dig + ((item * NPARTS + dj) * a.ext + sl) * n + th_off;
-        }
-        return a.conv + (((size_t)b * 2 + u) * a.nl + sl) * n + th_off;
-    };
-    // one forward row transform of x[] (inputs in registers), results reduced to |y| <= 0.51 q in this wave's LDS rows;
-    // `next` (may be null): inputs of the following transform, requested while this one's results are consumed
-    auto transform = [&](u64 (&x)[H], const u64 *next) {
-        {
-            u64 w[H - 1], wp[H - 1];
-            wave_lds_sync();  // twiddles staged (first transform) / previous transform's consumers finished with LDS
-            TA::fetch(twa, twa_sh, g, w, wp);
-            radix_forward_fp<LOG_H>(x, w, wp, q, qinv);
-        }
-        u64 w2[H - 1], wp2[H - 1];  // round-B twiddles: requested before the exchange, used after it
-        load_rowb_twiddles<LOG_H>(twb, row0 + g, j, w2, wp2);
-#pragma unroll
-        for (int k = 0; k < H; ++k) lds[TL::at(g, j + H * k)] = x[k];
-        wave_lds_sync();
-#pragma unroll
-        for (int k = 0; k < H; ++k) x[k] = lds[TL::at(g, H * j + k)];
-        radix_forward_fp<LOG_H>(x, w2, wp2, q, qinv);
-#pragma unroll
-        for (int k = 0; k < H; ++k) lds[TL::at(g, H * j + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));  // |y| <= 0.51 q
-        if (next) {
-#pragma unroll
-            for (int k = 0; k < H; ++k) x[k] = ld_stream(next + H * k);
-        }
-        wave_lds_sync();
-    };
-    u64 x[H];
-    {
-        const u64 *src = src_of(ND > 0 ? 0 : a.n_clients, 0);
-#pragma unroll
-        for (int k = 0; k < H; ++k) x[k] = ld_stream(src + H * k);
-    }
-#pragma unroll 1
-    for (uint32_t c = 0; c < a.n_clients; ++c) {
-        const u64 *ct = a.cts + (size_t)c * a.ct_cstride + (size_t)b * a.ct_stride + (size_t)sl * n + tile_off;
-        const u64 *ek = a.evk + (size_t)c * a.evk_cstride + (size_t)sl * n + tile_off;
-        {   // the digit that owns this limb: c1 itself (EVALUATION format); and c0 * P on component 0
-            const u64 *y1 = ct + (size_t)a.nl * n;
-            const u64 *e0 = ek + ((size_t)own * 2 + 0) * a.D * n, *e1 = ek + ((size_t)own * 2 + 1) * a.D * n;
-#pragma unroll
-            for (int i = 0; i < PAIRS; ++i) {
-                const int e = wave_pair<LOG_H>(i);
-                const ulong2 yy = ld_stream2(reinterpret_cast<const ulong2 *>(y1) + e);
-                const ulong2 zz = ld_stream2(reinterpret_cast<const ulong2 *>(ct) + e);
-                const ulong2 bb = reinterpret_cast<const ulong2 *>(e0)[e];
-                const ulong2 aa = reinterpret_cast<const ulong2 *>(e1)[e];
-                const double yx = u52_to_double(yy.x), yz = u52_to_double(yy.y);
-                acc0[i].x += fp_mulmod_any(yx, u52_to_double(bb.x), q, qinv) + fp_mulmod(u52_to_double(zz.x), pm, pmq, q);
-                acc0[i].y += fp_mulmod_any(yz, u52_to_double(bb.y), q, qinv) + fp_mulmod(u52_to_double(zz.y), pm, pmq, q);
-                acc1[i].x += fp_mulmod_any(yx, u52_to_double(aa.x), q, qinv);
-                acc1[i].y += fp_mulmod_any(yz, u52_to_double(aa.y), q, qinv);
-                if (NPARTS > 4 || ND == 0) {  // keeps the sums below 2^53 (see the bound below)
-                    acc0[i].x = fp_reduce(acc0[i].x, q, qinv);
-                    acc0[i].y = fp_reduce(acc0[i].y, q, qinv);
-                    acc1[i].x = fp_reduce(acc1[i].x, q, qinv);
-                    acc1[i].y = fp_reduce(acc1[i].y, q, qinv);
-                }
-            }
-        }
-#pragma unroll 1
-        for (int u = 0; u < ND; ++u) {
-            const bool last_u = u == ND - 1;
-            transform(x, last_u ? src_of(c + 1, 0) : src_of(c, u + 1));
-            const int dj = u < own ? u : u + 1;
-            const u64 *e0 = ek + ((size_t)dj * 2 + 0) * a.D * n, *e1 = ek + ((size_t)dj * 2 + 1) * a.D * n;
-            // per client the sums grow by at most 0.97 q (own digit) + 0.82 q (c0 P) + 0.75 q per converted digit on top
-            // of the 0.51 q carried over: < 3.8 q < 2^53 for up to 4 digits (5, 6 digits: the extra reduction above);
-            // the last digit's products end with the reduction that brings them back to 0.51 q
-#pragma unroll
-            for (int i = 0; i < PAIRS; ++i) {
-                const int e = wave_pair<LOG_H>(i);
-                const int gg = (2 * e) / R, xx = (2 * e) % R;
-                const ulong2 bb = reinterpret_cast<const ulong2 *>(e0)[e];
-                const ulong2 aa = reinterpret_cast<const ulong2 *>(e1)[e];
-                const double yx = bitsd(lds[TL::at(gg, xx)]), yz = bitsd(lds[TL::at(gg, xx + 1)]);
-                acc0[i].x += fp_mulmod_any(yx, u52_to_double(bb.x), q, qinv);
-                acc0[i].y += fp_mulmod_any(yz, u52_to_double(bb.y), q, qinv);
-                acc1[i].x += fp_mulmod_any(yx, u52_to_double(aa.x), q, qinv);
-                acc1[i].y += fp_mulmod_any(yz, u52_to_double(aa.y), q, qinv);
-                if (last_u) {
-                    acc0[i].x = fp_reduce(acc0[i].x, q, qinv);
-                    acc0[i].y = fp_reduce(acc0[i].y, q, qinv);
-                    acc1[i].x = fp_reduce(acc1[i].x, q, qinv);
-                    acc1[i].y = fp_reduce(acc1[i].y, q, qinv);
-                }
-            }
-        }
-    }
-    // ApproxModDown's conversions, summed over the clients: two transforms, subtracted (|acc| <= 0.51 q + 0.51 q)
-#pragma unroll 1
-    for (int comp = 0; comp < 2; ++comp) {
-        transform(x, comp == 0 ? src_of(a.n_clients, 1) : nullptr);
-#pragma unroll
-        for (int i = 0; i < PAIRS; ++i) {
-            const int e = wave_pair<LOG_H>(i);
-            const int gg = (2 * e) / R, xx = (2 * e) % R;
-            const double yx = bitsd(lds[TL::at(gg, xx)]), yz = bitsd(lds[TL::at(gg, xx + 1)]);
-            if (comp == 0) {
-                acc0[i].x -= yx;
-                acc0[i].y -= yz;
-            } else {
-                acc1[i].x -= yx;
-                acc1[i].y -= yz;
-            }
-        }
-    }
-    const double pi = bitsd(a.pq[4 * sl + 2]), piq = bitsd(a.pq[4 * sl + 3]);
-#pragma unroll
-    for (int i = 0; i < PAIRS; ++i) {
-        const int e = wave_pair<LOG_H>(i);
-        ulong2 r0, r1v;
-        r0.x = fp_to_canonical(fp_mulmod(acc0[i].x, pi, piq, q), q, qinv);
-        r0.y = fp_to_canonical(fp_mulmod(acc0[i].y, pi, piq, q), q, qinv);
-        r1v.x = fp_to_canonical(fp_mulmod(acc1[i].x, pi, piq, q), q, qinv);
-        r1v.y = fp_to_canonical(fp_mulmod(acc1[i].y, pi, piq, q), q, qinv);
-        reinterpret_cast<ulong2 *>(o0)[e] = r0;
-        reinterpret_cast<ulong2 *>(o1)[e] = r1v;
-    }
-}
-
-// The same kernel on the three-round row geometry (RowT<LOGC>: 8 words per thread, 256-point rows as 8 x 8 x 4): the
-// accumulators are 32 registers instead of 64, every twiddle of the limb's rows is staged once (rounds A, B in LDS,
-// round C in 28 registers) instead of being re-read from L2 per transform, and the kernel runs 3-4 waves per SIMD.
+// Three-round row geometry (RowT<LOGC>: 8 words per thread, 256-point rows as 8 x 8 x 4, 512-point rows as 8 x 8 x 8): the
+// accumulators are 32 registers, every twiddle of the limb's rows is staged once (rounds A, B in LDS, round C parked in
+// LDS too: MK_QSUM_PARK_C) instead of being re-read from L2 per transform, and the kernel runs 3 waves per SIMD.  (A
+// two-round form with 16 words per thread and 2 waves was 1.5 % slower and is gone.)
 template <int NPARTS, int LOGC, int MINW>
 __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttTables T) {
     using TL = RowT<LOGC>;
@@ -219,7 +50,6 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
     constexpr int NC = MK_QSUM_PARK_C ? (LOGC == 3 ? 7 : 6) : 0;
     __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
     __shared__ ulong2 ldsc[NC ? NC * NTT_THREADS : 1];
-    stagger_start<MINW, 12>(T.stagger * a.n_clients);  // lifetime grows with the client loop: 12 units per client and resident
     Row3Ctx c;
     c.lds = lds;
     c.twa = lds + TL::WORDS;
@@ -334,7 +164,10 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
             const int dj = u < own ? u : u + 1;
             const u64 *e0 = ek + ((size_t)dj * 2 + 0) * a.D * n, *e1 = ek + ((size_t)dj * 2 + 1) * a.D * n;
 #pragma unroll
-            for (int i = 0; i < PAIRS; ++i) {  // bounds: see k_qsum_fp
+            // per client the sums grow by at most 0.97 q (own digit) + 0.82 q (c0 P) + 0.75 q per converted digit on top
+            // of the 0.51 q carried over: < 3.8 q < 2^53 for up to 4 digits (5, 6 digits: the extra reduction above);
+            // the last digit's products end with the reduction that brings them back to 0.51 q
+            for (int i = 0; i < PAIRS; ++i) {
                 const int e = row3_pair<LOGC>(c.g, c.t, i);
                 const int xx = (2 * e) % R;
                 const ulong2 bb = reinterpret_cast<const ulong2 *>(e0)[e];
@@ -385,291 +218,6 @@ __global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3_fp(QSumArgs a, NttT
     t_mark = stm.add<3>(t_mark);
     stm.add<4>(t_begin);
     stm.flush<2>(T.stamps, false);
-}
-
-// k_qsum3_fp with the operand loads software-pipelined (round 3).  vmcnt retires loads IN ORDER, and k_qsum3_fp asked for
-// its operands where it used them: per client four groups of (c1, c0, b, a) tiles and per digit four groups of (b, a)
-// tiles, each group waited for on its own, the digit groups behind the next transform's input words (first touch, HBM
-// latency) that had been requested just before them -- about six exposed HBM and six L2 round trips per client and wave
-// at 3 waves per SIMD (valu_util 0.53, wait_any 0.60).  Here every operand is requested in the order it is consumed and
-// at least one phase ahead:
-//   digit phase u:  x <- xn;  request xn = inputs of the NEXT transform;  [F mode, last digit: request the next client's
-//                   own-digit tiles 0, 1];  transform(x);  products with E (requested at the end of the previous phase,
-//                   arrived during the transform);  request the next phase's E
-//   own phase:      products of c1 / c0 with the own digit's key tiles from G0 (tiles 0, 1) and G1 (tiles 2, 3)
-// F mode (MINW == 2, 256 registers): G0 is a register set of its own, requested a whole phase ahead; otherwise (3 waves,
-// 168 registers) tiles 0, 1 arrive in E (requested at the end of the last digit phase) and tiles 2, 3 are requested into
-// the same registers as tiles 0, 1 are consumed.  Needs at least one converted digit (NPARTS >= 2).
-template <int NPARTS, int LOGC, int MINW>
-__global__ __launch_bounds__(NTT_THREADS, MINW) void k_qsum3p_fp(QSumArgs a, NttTables T) {
-    using TL = RowT<LOGC>;
-    constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
-    constexpr int ND = NPARTS - 1;
-    constexpr bool FMODE = MINW <= 2;
-    constexpr bool PARK = !FMODE && MK_QSUM_PARK_C;
-    static_assert(ND >= 1, "the pipelined kernel needs a converted digit");
-    constexpr int NC = PARK ? (LOGC == 3 ? 7 : 6) : 0;
-    __shared__ u64 lds[TL::WORDS + 2 * (TL::TWA + TL::TWB)];
-    __shared__ ulong2 ldsc[NC ? NC * NTT_THREADS : 1];
-    stagger_start<MINW, 12>(T.stagger * a.n_clients);
-    Row3Ctx c;
-    c.lds = lds;
-    c.twa = lds + TL::WORDS;
-    c.twa_sh = c.twa + TL::TWA;
-    c.twb = c.twa_sh + TL::TWA;
-    c.twb_sh = c.twb + TL::TWB;
-    c.twc = ldsc;
-    const uint32_t n = 1u << T.log_n, r1 = 1u << T.log_r1;
-    const uint32_t tiles = r1 / S, groups = tiles * a.nsel;
-    uint32_t grp, b;
-    group_member(blockIdx.x, groups, a.cnt, T.cu_affine, grp, b);
-    const uint32_t sl = nth_set_bit(a.slot_mask, grp / tiles);
-    const LimbConst lc = T.limb[sl];
-    const int own = (int)(sl / a.alpha);
-    const uint32_t row0 = (grp % tiles) * S;
-    c.g = threadIdx.x / TPR;
-    c.t = threadIdx.x % TPR;
-    const u64 *tw = T.tw + (size_t)sl * n, *tw_sh = T.tw_sh + (size_t)sl * n;
-    row3_stage_twiddles<LOGC>(c, tw, tw_sh, r1 + row0);
-    u64 wc[7], wpc[7];
-    row3_load_c_twiddles<LOGC>(tw, tw_sh, r1 + row0 + c.g, c.t, wc, wpc);
-    if (PARK) {
-        row3_park_c_twiddles<LOGC>(c, wc, wpc);
-#pragma unroll
-        for (int i = 0; i < 7; ++i) wc[i] = wpc[i] = 0;
-    }
-    const size_t tile_off = (size_t)row0 * R;
-    const double q = lc.qd, qinv = lc.qinv;
-    const double pm = bitsd(a.pq[4 * sl]), pmq = bitsd(a.pq[4 * sl + 1]);
-    u64 *o0 = a.out + (size_t)b * a.out_stride + (size_t)sl * n + tile_off;
-    u64 *o1 = o0 + (size_t)a.nl * n;
-    double2 acc0[PAIRS], acc1[PAIRS];
-#pragma unroll
-    for (int i = 0; i < PAIRS; ++i) {
-        if (a.init_from_out) {
-            const int e = row3_pair<LOGC>(c.g, c.t, i);
-            const ulong2 v0 = reinterpret_cast<const ulong2 *>(o0)[e], v1 = reinterpret_cast<const ulong2 *>(o1)[e];
-            acc0[i].x = fp_mulmod(u52_to_double(v0.x), pm, pmq, q);
-            acc0[i].y = fp_mulmod(u52_to_double(v0.y), pm, pmq, q);
-            acc1[i].x = fp_mulmod(u52_to_double(v1.x), pm, pmq, q);
-            acc1[i].y = fp_mulmod(u52_to_double(v1.y), pm, pmq, q);
-        } else {
-            acc0[i] = double2{0.0, 0.0};
-            acc1[i] = double2{0.0, 0.0};
-        }
-    }
-    // addressing: wave-uniform tile bases (scalar registers) + ONE 32-bit per-thread word offset per access shape +
-    // compile-time constants -- 64-bit per-thread addresses for every load site cost ~80 registers
-    const uint32_t tx = (uint32_t)c.g * R + (uint32_t)c.t;       // 8-byte accesses: word tx + TPR k of the tile
-    const uint32_t tp = (uint32_t)c.g * R + 2u * (uint32_t)c.t;  // 16-byte accesses: words tp + 2 TPR i, +1
-    auto src_of = [&](uint32_t cl, int u) -> const u64 * {  // tile of the inputs of transform u of client cl; cl == n_clients: the conversions
-        if (cl < a.n_clients) {
-            const size_t item = (size_t)cl * a.cnt + b;
-            const int dj = u < own ? u : u + 1;
-            return a.dig + ((item * NPARTS + dj) * a.ext + sl) * n + tile_off;
-        }
-        return a.conv + (((size_t)b * 2 + u) * a.nl + sl) * n + tile_off;
-    };
-    auto ldt = [&](const u64 *tile, int i) { return *reinterpret_cast<const ulong2 *>(tile + (tp + 2u * TPR * i)); };
-    auto ldt_s = [&](const u64 *tile, int i) { return ld_stream2(reinterpret_cast<const ulong2 *>(tile + (tp + 2u * TPR * i))); };
-    // own-digit operands of client cl, tile pair i: (c1, c0, b_own, a_own)
-    auto req_own = [&](uint32_t cl, int i, ulong2 (&r)[4]) {
-        const u64 *ct = a.cts + (size_t)cl * a.ct_cstride + (size_t)b * a.ct_stride + (size_t)sl * n + tile_off;
-        const u64 *ek = a.evk + (size_t)cl * a.evk_cstride + (size_t)sl * n + tile_off + ((size_t)own * 2) * a.D * n;
-        r[0] = ldt_s(ct + (size_t)a.nl * n, i);
-        r[1] = ldt_s(ct, i);
-        r[2] = ldt(ek, i);
-        r[3] = ldt(ek + (size_t)a.D * n, i);
-    };
-    auto mac_own = [&](int i, const ulong2 (&r)[4]) {
-        const double yx = u52_to_double(r[0].x), yz = u52_to_double(r[0].y);
-        acc0[i].x += fp_mulmod_any(yx, u52_to_double(r[2].x), q, qinv) + fp_mulmod(u52_to_double(r[1].x), pm, pmq, q);
-        acc0[i].y += fp_mulmod_any(yz, u52_to_double(r[2].y), q, qinv) + fp_mulmod(u52_to_double(r[1].y), pm, pmq, q);
-        acc1[i].x += fp_mulmod_any(yx, u52_to_double(r[3].x), q, qinv);
-        acc1[i].y += fp_mulmod_any(yz, u52_to_double(r[3].y), q, qinv);
-        if (NPARTS > 4) {  // keeps the sums below 2^53 (bounds: k_qsum_fp)
-            acc0[i].x = fp_reduce(acc0[i].x, q, qinv);
-            acc0[i].y = fp_reduce(acc0[i].y, q, qinv);
-            acc1[i].x = fp_reduce(acc1[i].x, q, qinv);
-            acc1[i].y = fp_reduce(acc1[i].y, q, qinv);
-        }
-    };
-    ulong2 E[8];    // digit phase: (b, a) of tile pairs 0..3; own phase: tiles 2, 3 (F mode) or 0, 1 then 2, 3
-    ulong2 F[8];    // F mode: the own phase's tiles 0, 1
-    u64 x[8], xn[8];
-    {
-        const u64 *src = src_of(0, 0);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) xn[k] = ld_stream(src + (tx + (uint32_t)TPR * k));
-    }
-    if (FMODE) {
-        ulong2 r[4];
-        req_own(0, 0, r);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) F[k] = r[k];
-        req_own(0, 1, r);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) F[4 + k] = r[k];
-        req_own(0, 2, r);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) E[k] = r[k];
-        req_own(0, 3, r);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) E[4 + k] = r[k];
-    } else {
-        ulong2 r[4];
-        req_own(0, 0, r);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) E[k] = r[k];
-        req_own(0, 1, r);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) E[4 + k] = r[k];
-    }
-    __syncthreads();  // twiddles staged
-#pragma unroll 1
-    for (uint32_t cl = 0; cl < a.n_clients; ++cl) {
-        const u64 *ek = a.evk + (size_t)cl * a.evk_cstride + (size_t)sl * n + tile_off;
-        {   // own phase
-            ulong2 r[4];
-            if (FMODE) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) r[k] = F[4 * i + k];
-                    mac_own(i, r);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) r[k] = E[4 * i + k];
-                    mac_own(2 + i, r);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {  // tiles 0, 1 out of E; tiles 2, 3 requested into the registers they free
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) r[k] = E[4 * i + k];
-                    mac_own(i, r);
-                    req_own(cl, 2 + i, r);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) E[4 * i + k] = r[k];
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) r[k] = E[4 * i + k];
-                    mac_own(2 + i, r);
-                }
-            }
-            // the first digit's key tiles
-            const int dj = 0 < own ? 0 : 1;
-            const u64 *e0 = ek + ((size_t)dj * 2) * a.D * n, *e1 = e0 + (size_t)a.D * n;
-#pragma unroll
-            for (int i = 0; i < PAIRS; ++i) {
-                E[2 * i] = ldt(e0, i);
-                E[2 * i + 1] = ldt(e1, i);
-            }
-        }
-        int nd = ND;
-        if (ND == 1) asm volatile("" : "+s"(nd));  // keep the digit loop a loop (see k_qsum3_fp)
-#pragma unroll 1
-        for (int u = 0; u < nd; ++u) {
-            const bool last_u = u == ND - 1;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = xn[k];
-            {
-                const u64 *next = last_u ? src_of(cl + 1, 0) : src_of(cl, u + 1);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) xn[k] = ld_stream(next + (tx + (uint32_t)TPR * k));
-            }
-            if (FMODE && last_u && cl + 1 < a.n_clients) {
-                ulong2 r[4];
-                req_own(cl + 1, 0, r);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) F[k] = r[k];
-                req_own(cl + 1, 1, r);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) F[4 + k] = r[k];
-            }
-            wave_lds_sync();  // the previous transform's consumers finished reading this wave's rows
-            row3_forward<AR_FP, LOGC, PARK>(x, c, wc, wpc, lc);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 8 * c.t + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));
-            wave_lds_sync();
-#pragma unroll
-            for (int i = 0; i < PAIRS; ++i) {  // bounds: see k_qsum_fp
-                const int xx = (2 * row3_pair<LOGC>(c.g, c.t, i)) % R;
-                const ulong2 bb = E[2 * i], aa = E[2 * i + 1];
-                const double yx = bitsd(lds[TL::at(c.g, xx)]), yz = bitsd(lds[TL::at(c.g, xx + 1)]);
-                acc0[i].x += fp_mulmod_any(yx, u52_to_double(bb.x), q, qinv);
-                acc0[i].y += fp_mulmod_any(yz, u52_to_double(bb.y), q, qinv);
-                acc1[i].x += fp_mulmod_any(yx, u52_to_double(aa.x), q, qinv);
-                acc1[i].y += fp_mulmod_any(yz, u52_to_double(aa.y), q, qinv);
-                if (last_u) {
-                    acc0[i].x = fp_reduce(acc0[i].x, q, qinv);
-                    acc0[i].y = fp_reduce(acc0[i].y, q, qinv);
-                    acc1[i].x = fp_reduce(acc1[i].x, q, qinv);
-                    acc1[i].y = fp_reduce(acc1[i].y, q, qinv);
-                }
-            }
-            if (!last_u) {  // the next digit's key tiles
-                const int dj = (u + 1) < own ? (u + 1) : (u + 2);
-                const u64 *e0 = ek + ((size_t)dj * 2) * a.D * n, *e1 = e0 + (size_t)a.D * n;
-#pragma unroll
-                for (int i = 0; i < PAIRS; ++i) {
-                    E[2 * i] = ldt(e0, i);
-                    E[2 * i + 1] = ldt(e1, i);
-                }
-            } else if (cl + 1 < a.n_clients) {  // the next client's own-digit tiles: 2, 3 (F mode) or 0, 1
-                ulong2 r[4];
-                req_own(cl + 1, FMODE ? 2 : 0, r);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) E[k] = r[k];
-                req_own(cl + 1, FMODE ? 3 : 1, r);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) E[4 + k] = r[k];
-            }
-        }
-    }
-#pragma unroll 1
-    for (int comp = 0; comp < 2; ++comp) {  // the summed ModDown conversions
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = xn[k];
-        if (comp == 0) {
-            const u64 *next = src_of(a.n_clients, 1);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) xn[k] = ld_stream(next + (tx + (uint32_t)TPR * k));
-        }
-        wave_lds_sync();
-        row3_forward<AR_FP, LOGC, PARK>(x, c, wc, wpc, lc);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) lds[TL::at(c.g, 8 * c.t + k)] = dbits(fp_reduce(bitsd(x[k]), q, qinv));
-        wave_lds_sync();
-#pragma unroll
-        for (int i = 0; i < PAIRS; ++i) {
-            const int xx = (2 * row3_pair<LOGC>(c.g, c.t, i)) % R;
-            const double yx = bitsd(lds[TL::at(c.g, xx)]), yz = bitsd(lds[TL::at(c.g, xx + 1)]);
-            if (comp == 0) {
-                acc0[i].x -= yx;
-                acc0[i].y -= yz;
-            } else {
-                acc1[i].x -= yx;
-                acc1[i].y -= yz;
-            }
-        }
-    }
-    const double pi = bitsd(a.pq[4 * sl + 2]), piq = bitsd(a.pq[4 * sl + 3]);
-#pragma unroll
-    for (int i = 0; i < PAIRS; ++i) {
-        const int e = row3_pair<LOGC>(c.g, c.t, i);
-        ulong2 r0, r1v;
-        r0.x = fp_to_canonical(fp_mulmod(acc0[i].x, pi, piq, q), q, qinv);
-        r0.y = fp_to_canonical(fp_mulmod(acc0[i].y, pi, piq, q), q, qinv);
-        r1v.x = fp_to_canonical(fp_mulmod(acc1[i].x, pi, piq, q), q, qinv);
-        r1v.y = fp_to_canonical(fp_mulmod(acc1[i].y, pi, piq, q), q, qinv);
-        reinterpret_cast<ulong2 *>(o0)[e] = r0;
-        reinterpret_cast<ulong2 *>(o1)[e] = r1v;
-    }
 }
 
 }  // namespace mk

@@ -465,37 +465,19 @@ def test_reencrypt_sum(ctxs, name, nl, C, B):
         assert np.array_equal(got[b], acc)
 
 
-@pytest.mark.parametrize("env", [{"MKCKKS_FUSE_INNER": "0"}, {"MKCKKS_SUM_PAIR": "0"},
-                                 {"MKCKKS_FUSE_INNER": "0", "MKCKKS_SUM_PAIR": "0"},
-                                 {"MKCKKS_ROW3X": "1"},  # three-round instead of two-round 256-point kernels
-                                 {"MKCKKS_FUSE_INNER_INT": "0"},  # integer limbs: separate row pass + inner product
-                                 {"MKCKKS_FUSE_P_INVERSE": "0"},  # P limbs: accumulators to HBM, separate inverse row pass
-                                 {"MKCKKS_CONV_FP": "0"},         # conversion sources as packed 30-bit halves for every target
-                                 {"MKCKKS_QSUM": "0"},            # per-client key switch on two lanes + k_row_tail_sum2
-                                 {"MKCKKS_QSUM": "0", "MKCKKS_SUM_ONE_LANE": "1"},
-                                 {"MKCKKS_QSUM_GROUP": "2"},      # merged flow, clients in groups of 2 (running sum in out)
+@pytest.mark.parametrize("env", [{"MKCKKS_QSUM_GROUP": "2"},      # merged flow, clients in groups of 2 (running sum in out)
                                  {"MKCKKS_QSUM_GROUP": "1"},
-                                 {"MKCKKS_QSUM_GEOM": "2"},       # two-round k_qsum_fp (16 words per thread)
-                                 {"MKCKKS_QSUM_GEOM": "2", "MKCKKS_QSUM_GROUP": "2"},
-                                 {"MKCKKS_SUM_ONE_LANE": "1"},    # clients strictly one after the other
-                                 {"MKCKKS_NO_PM": "1"},           # Shoup butterflies on q_0 and the P limbs
-                                 {"MKCKKS_NO_PM": "1", "MKCKKS_QSUM": "0"},
-                                 {"MKCKKS_QSUM_GEOM": "4"},       # three-round k_qsum3_fp at 2 waves per SIMD
-                                 {"MKCKKS_QSUM_PIPE": "1"},       # k_qsum3p_fp: operand loads software-pipelined, 3 waves
-                                 {"MKCKKS_QSUM_PIPE": "2"},       # ... 2 waves, own-digit tiles a whole phase ahead
-                                 {"MKCKKS_QSUM_PIPE": "1", "MKCKKS_QSUM_GROUP": "2"},
-                                 {"MKCKKS_CONV_LDS": "1"},        # ModUp conversion out of LDS, all targets of a digit per workgroup (k_conv_lds)
-                                 {"MKCKKS_CONV_PAIR2": "3"},      # ModUp conversion: two targets of a class per workgroup (k_conv_col2)
-                                 {"MKCKKS_CONV_PAIR2": "1"},
+                                 {"MKCKKS_CHUNK": "2"},           # workspace chunks of 2 ciphertext indices
                                  {"MKCKKS_CU_AFFINE": "0"},       # plain XCD-aware placement of the workgroups that share tiles
-                                 {"MKCKKS_STAGGER": "100"},       # start-phase stagger of every pass's first generation
-                                 {"MKCKKS_NO_FP64": "1"},         # integer (Shoup) arithmetic on every limb
-                                 {"MKCKKS_NO_FP64": "1", "MKCKKS_QSUM": "0"},
+                                 {"MKCKKS_NO_PM": "1"},           # Shoup butterflies on q_0 and the P limbs (any 60-bit modulus)
+                                 {"MKCKKS_NO_FP64": "1"},         # integer arithmetic on every limb: no merged flow, per-client loop
+                                 {"MKCKKS_NO_FP64": "1", "MKCKKS_NO_PM": "1"},
                                  {"MKCKKS_GENERIC_NTT": "1"}])    # LDS-stage kernels for both passes, nothing fused
 def test_unfused_kernel_paths_stay_bit_exact(ctxs, monkeypatch, env):
-    """Every non-default kernel path the library keeps behind a switch (other ring sizes fall back to them, A/B
-    measurements use them): a context created under the switch must give the same bits as the default context and as
-    the oracle at N = 2^16.  Switches are read once, when a context is created."""
+    """The switches the library keeps select tuning parameters (chunk, client group, placement) or the arithmetic /
+    kernel families that other moduli and ring sizes fall back to (Shoup instead of pseudo-Mersenne, integer instead of
+    fp64, LDS-stage transforms): a context created under the switch must give the same bits as the default context and
+    as the oracle at N = 2^16.  Switches are read once, when a context is created."""
     from ppqsflhe_amd import Context
     g, o = ctxs("c3")
     nl, C, B = 12, 3, 1
@@ -524,7 +506,7 @@ def test_unfused_kernel_paths_stay_bit_exact(ctxs, monkeypatch, env):
 
 def test_fused_path_across_workspace_chunks(ctxs, monkeypatch):
     """N = 2^16 with a workspace chunk of 2 ciphertexts: 3 ciphertexts per client take one full and one partial chunk
-    through the fused kernels (reencrypt_sum with two client lanes, and the single-client reencrypt)."""
+    through the fused kernels (the merged n-client flow of reencrypt_sum, and the single-client reencrypt)."""
     from ppqsflhe_amd import Context
     _, o = ctxs("c3")
     a = CONFIGS["c3"]
@@ -856,6 +838,51 @@ def test_config4_sixty_four_clients_on_one_rank(ctxs):
     assert np.array_equal(agg[0].cpu().numpy().view(np.uint64), acc)
     exp = o.mult_factors(o.rescale(acc), o.const_factors(L - 1, 1, 1.0 / C))
     assert np.array_equal(avg[0].cpu().numpy().view(np.uint64), exp)
+
+
+def test_async_copies_pinned_buffers_and_range_check(ctxs):
+    """The I/O pipeline entry points of the C-ABI (include/mkckks.h: host_alloc, upload_async / download_async with
+    tickets, fences, count_noncanonical): ciphertexts travel pinned buffer -> HBM on the upload stream, are re-encrypted on
+    the compute stream behind fence_uploads, and come back on the download stream behind fence_compute -- the same bits as
+    the synchronous path.  A residue at or above its modulus is counted on the device."""
+    from ppqsflhe_amd import MkckksError
+    g, o = ctxs("ref")
+    rng = np.random.default_rng(31)
+    nl, B = g.L, 6
+    cts = rand_ct(rng, g, nl, B)
+    evk = rand_polys(rng, g, list(range(g.D)) * (2 * g.beta), 1).reshape(g.beta, 2, g.D, g.N)
+    d_evk = g.to_device(evk)
+    d_in, d_out = g.empty((B, 2, nl, g.N)), g.empty((B, 2, nl, g.N))
+    one = cts[0].nbytes
+    pin = g.host_alloc(2 * one)          # two slots: the classic double buffer
+    back = g.host_alloc(B * one)
+    tickets = []
+    for b in range(B):
+        slot = pin[(b % 2) * one:(b % 2 + 1) * one]
+        if b >= 2:
+            g.copy_wait(tickets[b - 2])   # the slot's previous upload is over before it is refilled
+        slot[:] = np.frombuffer(cts[b].tobytes(), dtype=np.uint8)
+        tickets.append(g.upload_async(d_in.ptr + b * one, slot))
+    assert tickets == sorted(tickets) and tickets[0] >= 1
+    g.fence_uploads()
+    assert g.count_noncanonical(d_in, B, nl) == 0
+    g.reencrypt(d_in, d_evk, d_out, B, nl)
+    g.fence_compute()
+    t = g.download_async(back, d_out)
+    g.copy_wait(t)
+    assert g.copy_done(t) and all(g.copy_done(x) for x in tickets)
+    got = np.frombuffer(back.tobytes(), dtype=np.uint64).reshape(B, 2, nl, g.N)
+    for b in (0, 3, 5):
+        assert np.array_equal(got[b], o.reencrypt(cts[b], evk))
+    # two residues out of range -> counted, nothing else
+    bad = cts.copy()
+    bad[1, 0, 0, 5] = g.moduli[0]
+    bad[4, 1, nl - 1, 9] = np.uint64(2**64 - 1)
+    assert g.count_noncanonical(g.to_device(bad), B, nl) == 2
+    with pytest.raises(MkckksError):
+        g.copy_wait(10**9)               # a ticket that was never issued
+    g.host_free(pin)
+    g.host_free(back)
 
 
 def test_rccl_reduce_scatter_through_the_cabi(ctxs):

@@ -9,10 +9,13 @@
 //   * the file is INDEXED, not loaded: skeleton JSON + (offset, size) of every ciphertext container;
 //   * reader threads pread() ciphertext payloads straight into a ring of PINNED slots (mkckks_host_alloc); the main
 //     thread enqueues each filled slot on the context's upload stream (mkckks_upload_async) and recycles it when its
-//     ticket is done -- reading file k+1 overlaps the upload of file k, no pageable staging copy in between;
-//   * residues are range-checked on the DEVICE (mkckks_count_noncanonical) instead of in a host loop, headers on the host;
-//   * results come back through pinned slots on the download stream and are written with pwrite() by writer threads at
-//     offsets known in advance -- the output file is byte-identical to what write_envelope() produces.
+//     ticket is done -- no pageable staging copy in between;
+//   * the round runs by chunks of ciphertext indices (run_round_pipeline): re-encryption + sum + scaling of chunk c are
+//     enqueued behind its uploads (mkckks_fence_uploads) while chunk c+1 is being read and uploaded;
+//   * results come back into a pinned buffer on the download stream (mkckks_fence_compute, mkckks_download_async) and are
+//     written with pwrite() by writer threads at offsets known in advance -- the output file is byte-identical to what
+//     write_envelope() produces;
+//   * residues are range-checked on the DEVICE (mkckks_count_noncanonical) instead of in a host loop, headers on the host.
 // One host thread drives the context; the other threads only touch file descriptors and pinned memory.
 #pragma once
 #include <fcntl.h>
@@ -181,110 +184,6 @@ private:
     unsigned n_ = 0;
 };
 
-// one ciphertext container to bring into HBM: header to `hdr`, residues to d_dst
-struct LoadJob {
-    int fd;
-    BlobRef blob;
-    uint64_t *d_dst;
-    BlobHeader hdr;
-};
-
-// read every job's payload into a pinned slot (reader threads) and upload it (this thread); returns when every upload
-// has completed.  payload_bytes: what every container must carry after its header (all ciphertexts of a round have one
-// shape; a container of another size is refused).
-inline void load_ciphertexts(Session &s, PinnedRing &ring, std::vector<LoadJob> &jobs, size_t payload_bytes, unsigned threads) {
-    if (jobs.empty()) return;
-    if (payload_bytes > ring.slot_bytes()) throw std::logic_error("pinned slot smaller than a ciphertext");
-    std::mutex m;
-    std::condition_variable cv_free, cv_filled;
-    std::deque<unsigned> free_slots;
-    std::deque<std::pair<unsigned, size_t>> filled;  // (slot, job)
-    for (unsigned i = 0; i < ring.count(); ++i) free_slots.push_back(i);
-    std::atomic<size_t> next{0};
-    std::exception_ptr err;
-    bool stop = false;
-    auto reader = [&] {
-        try {
-            for (size_t j; (j = next.fetch_add(1)) < jobs.size();) {
-                unsigned slot;
-                {
-                    std::unique_lock<std::mutex> g(m);
-                    cv_free.wait(g, [&] { return stop || !free_slots.empty(); });
-                    if (stop) return;
-                    slot = free_slots.front();
-                    free_slots.pop_front();
-                }
-                LoadJob &job = jobs[j];
-                if (job.blob.size != sizeof(BlobHeader) + payload_bytes) throw std::runtime_error("ciphertext blob has the wrong size");
-                pread_all(job.fd, &job.hdr, sizeof(BlobHeader), job.blob.offset);
-                pread_all(job.fd, ring.slot(slot), payload_bytes, job.blob.offset + sizeof(BlobHeader));
-                {
-                    std::lock_guard<std::mutex> g(m);
-                    filled.emplace_back(slot, j);
-                }
-                cv_filled.notify_one();
-            }
-        } catch (...) {
-            std::lock_guard<std::mutex> g(m);
-            if (!err) err = std::current_exception();
-            stop = true;
-            cv_filled.notify_all();
-            cv_free.notify_all();
-        }
-    };
-    std::vector<std::thread> pool;
-    const unsigned nthr = (unsigned)std::min<size_t>(std::max(1u, threads), jobs.size());
-    for (unsigned t = 0; t < nthr; ++t) pool.emplace_back(reader);
-    std::deque<std::pair<uint64_t, unsigned>> in_flight;  // (ticket, slot), in ticket order
-    size_t uploaded = 0;
-    std::exception_ptr main_err;
-    try {
-        while (uploaded < jobs.size() || !in_flight.empty()) {
-            std::pair<unsigned, size_t> got{0, 0};
-            bool have = false;
-            {
-                std::unique_lock<std::mutex> g(m);
-                if (stop) break;
-                if (filled.empty() && uploaded < jobs.size())
-                    cv_filled.wait_for(g, std::chrono::microseconds(in_flight.empty() ? 2000 : 50));
-                if (!filled.empty()) {
-                    got = filled.front();
-                    filled.pop_front();
-                    have = true;
-                }
-            }
-            if (have) {
-                uint64_t ticket = 0;
-                Session::check(mkckks_upload_async(s.ctx(), jobs[got.second].d_dst, ring.slot(got.first), payload_bytes, &ticket));
-                in_flight.emplace_back(ticket, got.first);
-                ++uploaded;
-            }
-            while (!in_flight.empty()) {  // uploads complete in ticket order
-                int done = 0;
-                if (uploaded == jobs.size() && !have) Session::check(mkckks_copy_wait(s.ctx(), in_flight.front().first)), done = 1;
-                else Session::check(mkckks_copy_done(s.ctx(), in_flight.front().first, &done));
-                if (!done) break;
-                {
-                    std::lock_guard<std::mutex> g(m);
-                    free_slots.push_back(in_flight.front().second);
-                }
-                cv_free.notify_one();
-                in_flight.pop_front();
-            }
-        }
-    } catch (...) {
-        main_err = std::current_exception();
-    }
-    {
-        std::lock_guard<std::mutex> g(m);
-        stop = stop || main_err != nullptr;
-    }
-    cv_free.notify_all();
-    for (std::thread &t : pool) t.join();
-    if (main_err) std::rethrow_exception(main_err);
-    if (err) std::rethrow_exception(err);
-}
-
 // header checks of validate_ct() for a container that went straight to the device; residues are checked there
 inline Ciphertext meta_of(const BlobHeader &h, const Session &s) {
     if (std::memcmp(h.magic, "MKCK", 4) || h.version != 1 || h.kind != KIND_CT)
@@ -374,6 +273,357 @@ inline void write_envelope_from_device(Session &s, PinnedRing &ring, const std::
             pwrite_all(fd, ring.slot((unsigned)i), payload, at + sizeof pre);
         });
     }
+}
+
+// ---- the whole round as one pipeline ---------------------------------------------------------------------------------
+// file -> pinned slot -> HBM -> re-encrypt + sum + scale -> pinned buffer -> file, by CHUNKS of ciphertext indices: while
+// chunk c is being re-encrypted the reader threads and the upload stream bring chunk c+1, and the download stream and the
+// writer threads take chunk c-1 away.  A 12 MiB ciphertext is used once, so the host link is the wall of this program
+// (PCIe: ~3.3 k ciphertexts/s at 12.6 MB each); the point of the chunks is that nothing else adds to it.
+// One thread (the caller) drives the context; reader and writer threads only touch file descriptors and pinned memory.
+struct RoundTimes {
+    double setup = 0, round = 0;                  // ms: buffers + keys (once per process) | first read -> last byte written
+    double last_upload = 0, last_download = 0;    // ms since the round started
+    double read_busy = 0, write_busy = 0;         // ms summed over the reader / writer threads
+    unsigned chunk = 0;
+};
+
+struct RoundPlan {
+    size_t n_clients = 0, n_pre = 0;          // clients in `order`; the first n_pre carry a re-encryption key
+    const std::vector<EnvelopeIndex> *idx = nullptr;
+    const std::vector<AggItem> *items = nullptr;
+    const uint64_t *evks = nullptr;           // host [n_pre][beta][2][D][N]
+    size_t evk_words = 0;
+    unsigned threads = 4;
+};
+
+inline unsigned round_chunk(size_t B) {
+    unsigned c = 4;
+    if (const char *e = std::getenv("MKCKKS_ROUND_CHUNK")) c = (unsigned)std::max(1, std::atoi(e));
+    return (unsigned)std::min<size_t>(c, B);
+}
+
+// aggregate of all clients' ciphertexts, scaled by 1/n, left in HBM ([B][2][meta.nl][N], for the --back leg) and written
+// to `path` as an MKWS envelope -- the same bytes as the synchronous path (tests/test_cli_hosts.py)
+inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc, const std::string &path,
+                                    std::unique_ptr<PinnedRing> &ring, RoundTimes &tm) {
+    const double t_setup0 = now_ms();
+    const std::vector<AggItem> &items = *plan.items;
+    const std::vector<EnvelopeIndex> &idx = *plan.idx;
+    const uint32_t N = s.N();
+    const size_t B = items.size(), n_clients = plan.n_clients, n_pre = plan.n_pre, n_plain = n_clients - n_pre;
+    // shape of the round from the first container's header; every other one must carry the same payload size
+    BlobHeader h0;
+    const BlobRef &blob0 = idx[0].blobs.at(blob_index(*items[0].blobs[0]));
+    if (blob0.size < sizeof(BlobHeader)) throw std::runtime_error("ciphertext blob too short");
+    pread_all(idx[0].fd, &h0, sizeof h0, blob0.offset);
+    const Ciphertext first = meta_of(h0, s);
+    const uint32_t nl = first.nl;
+    const size_t words = (size_t)2 * nl * N, in_bytes = words * 8;
+    const unsigned Bc = round_chunk(B);
+    tm.chunk = Bc;
+    // result shape (scale_aggregate's rules)
+    AggResult agg;
+    Ciphertext &res = agg.meta;
+    const bool rescale = first.noise_deg == 2;
+    if (rescale && nl < 2) throw std::runtime_error("ciphertext has no limb left to rescale");
+    res.nl = rescale ? nl - 1 : nl;
+    res.level = rescale ? first.level + 1 : first.level;
+    res.scale = rescale ? first.scale / (double)s.moduli()[nl - 1] * s.sf(res.level, false) : first.scale * s.sf(first.level, false);
+    res.noise_deg = rescale ? 2 : first.noise_deg + 1;
+    res.slots = first.slots;
+    const size_t owords = (size_t)2 * res.nl * N, out_bytes = owords * 8;
+    // device: per chunk of cnt indices [re-keyed clients][slot for their sum][clients already in the domain] x [cnt], so that
+    // every chunk is what mkckks_reencrypt_sum_batch / mkckks_eval_sum_batch take; sums and outputs [B]
+    uint64_t *d_all = s.alloc<uint64_t>((n_clients + 1) * B * words);
+    uint64_t *d_sum = s.alloc<uint64_t>(B * words);  // sums over all clients, [B]
+    uint64_t *d_out = rescale ? s.alloc<uint64_t>(B * owords) : nullptr;
+    uint64_t *d_evk = n_pre ? s.to_device(plan.evks, n_pre * plan.evk_words) : nullptr;
+    ring.reset(new PinnedRing(s, in_bytes, std::max(4u, std::min<unsigned>(16u, 2 * plan.threads))));
+    PinnedRing out_pin(s, out_bytes, (unsigned)B);
+    // output file: skeleton with "@<item>" fields, sized in advance, blobs written at fixed offsets
+    for (size_t b = 0; b < B; ++b) {
+        Json &lay = doc["weights_summary"].a[items[b].out_layer];
+        Json ref("@" + std::to_string(b));
+        if (items[b].field == 0) lay["mean"] = ref;
+        else if (items[b].field == 1) lay["std_dev"] = ref;
+        else lay["values"].a[items[b].idx] = ref;
+    }
+    {
+        size_t k = 0;
+        for_each_ct_field(doc, [&](Json &field) {
+            if (field.as_string() != "@" + std::to_string(k)) throw std::logic_error("envelope fields out of item order");
+            ++k;
+        });
+        if (k != B) throw std::logic_error("envelope holds ciphertext fields that are not aggregate items");
+    }
+    std::string head("MKWS", 4);
+    {
+        std::string text;
+        doc.dump(text, 2);
+        const uint32_t version = 1;
+        const uint64_t skel_len = text.size(), n_blobs = B;
+        head.append(reinterpret_cast<const char *>(&version), 4);
+        head.append(reinterpret_cast<const char *>(&skel_len), 8);
+        head += text;
+        head.append(reinterpret_cast<const char *>(&n_blobs), 8);
+    }
+    const uint64_t blobs0 = head.size(), blob_size = sizeof(BlobHeader) + out_bytes;
+    const BlobHeader out_hdr = header_of(res, N);
+    tm.setup = now_ms() - t_setup0;
+
+    const double t0 = now_ms();
+    const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) throw std::runtime_error("cannot write " + path);
+    struct Closer {
+        int fd;
+        ~Closer() { ::close(fd); }
+    } closer{fd};
+    if (::ftruncate(fd, (off_t)(blobs0 + B * (8 + blob_size))) != 0) throw std::runtime_error("cannot size " + path);
+    pwrite_all(fd, head.data(), head.size(), 0);
+
+    // jobs in chunk order: chunk, client, index within the chunk
+    struct Job {
+        int fd;
+        BlobRef blob;
+        uint64_t *d_dst;
+        BlobHeader hdr;
+        unsigned chunk;
+    };
+    std::vector<Job> jobs;
+    jobs.reserve(n_clients * B);
+    std::vector<size_t> chunk_b0;
+    for (size_t b0 = 0; b0 < B; b0 += Bc) chunk_b0.push_back(b0);
+    const size_t n_chunks = chunk_b0.size();
+    auto chunk_cnt = [&](size_t c) { return std::min<size_t>(Bc, B - chunk_b0[c]); };
+    auto chunk_base = [&](size_t c) { return d_all + (n_clients + 1) * chunk_b0[c] * words; };
+    for (size_t c = 0; c < n_chunks; ++c) {
+        const size_t cnt = chunk_cnt(c);
+        for (size_t k = 0; k < n_clients; ++k)
+            for (size_t i = 0; i < cnt; ++i) {
+                const size_t b = chunk_b0[c] + i, bi = blob_index(*items[b].blobs[k]);
+                const size_t slot_k = k < n_pre ? k : k + 1;  // position n_pre is the sum slot
+                jobs.push_back(Job{idx[k].fd, idx[k].blobs.at(bi), chunk_base(c) + (slot_k * cnt + i) * words, BlobHeader{}, (unsigned)c});
+            }
+    }
+
+    std::mutex m;
+    std::condition_variable cv_free, cv_event, cv_write;
+    std::deque<unsigned> free_slots;
+    std::deque<std::pair<unsigned, size_t>> filled;  // (slot, job)
+    std::deque<size_t> to_write;                      // output index b, downloaded
+    for (unsigned i = 0; i < ring->count(); ++i) free_slots.push_back(i);
+    std::atomic<size_t> next{0};
+    std::exception_ptr err;
+    bool stop = false, writes_closed = false;
+    double read_busy = 0, write_busy = 0;
+    auto fail_from_thread = [&] {
+        std::lock_guard<std::mutex> g(m);
+        if (!err) err = std::current_exception();
+        stop = true;
+        cv_event.notify_all();
+        cv_free.notify_all();
+        cv_write.notify_all();
+    };
+    auto reader = [&] {
+        double busy = 0;
+        try {
+            for (size_t j; (j = next.fetch_add(1)) < jobs.size();) {
+                unsigned slot;
+                {
+                    std::unique_lock<std::mutex> g(m);
+                    cv_free.wait(g, [&] { return stop || !free_slots.empty(); });
+                    if (stop) return;
+                    slot = free_slots.front();
+                    free_slots.pop_front();
+                }
+                const double tb = now_ms();
+                Job &job = jobs[j];
+                if (job.blob.size != sizeof(BlobHeader) + in_bytes) throw std::runtime_error("ciphertext blob has the wrong size");
+                pread_all(job.fd, &job.hdr, sizeof(BlobHeader), job.blob.offset);
+                pread_all(job.fd, ring->slot(slot), in_bytes, job.blob.offset + sizeof(BlobHeader));
+                busy += now_ms() - tb;
+                {
+                    std::lock_guard<std::mutex> g(m);
+                    filled.emplace_back(slot, j);
+                }
+                cv_event.notify_one();
+            }
+        } catch (...) {
+            fail_from_thread();
+        }
+        std::lock_guard<std::mutex> g(m);
+        read_busy += busy;
+    };
+    auto writer = [&] {
+        double busy = 0;
+        try {
+            for (;;) {
+                size_t b;
+                {
+                    std::unique_lock<std::mutex> g(m);
+                    cv_write.wait(g, [&] { return stop || writes_closed || !to_write.empty(); });
+                    if (stop) return;
+                    if (to_write.empty()) break;  // closed and drained
+                    b = to_write.front();
+                    to_write.pop_front();
+                }
+                const double tb = now_ms();
+                const uint64_t at = blobs0 + b * (8 + blob_size);
+                char pre[8 + sizeof(BlobHeader)];
+                std::memcpy(pre, &blob_size, 8);
+                std::memcpy(pre + 8, &out_hdr, sizeof out_hdr);
+                pwrite_all(fd, pre, sizeof pre, at);
+                pwrite_all(fd, out_pin.slot((unsigned)b), out_bytes, at + sizeof pre);
+                busy += now_ms() - tb;
+            }
+        } catch (...) {
+            fail_from_thread();
+        }
+        std::lock_guard<std::mutex> g(m);
+        write_busy += busy;
+    };
+    std::vector<std::thread> pool;
+    const unsigned n_readers = (unsigned)std::min<size_t>(std::max(1u, plan.threads), jobs.size());
+    const unsigned n_writers = std::max(1u, std::min(4u, plan.threads));
+    for (unsigned t = 0; t < n_readers; ++t) pool.emplace_back(reader);
+    for (unsigned t = 0; t < n_writers; ++t) pool.emplace_back(writer);
+
+    std::exception_ptr main_err;
+    try {
+        std::deque<std::pair<uint64_t, unsigned>> up_flight;   // (ticket, ring slot)
+        std::deque<std::pair<uint64_t, size_t>> down_flight;   // (ticket, output index)
+        std::vector<size_t> enq(n_chunks, 0);
+        size_t uploaded = 0, computed = 0, downloaded = 0;
+        const double operand = 1.0 / (double)n_clients;
+        while (downloaded < B) {
+            bool progress = false;
+            std::pair<unsigned, size_t> got{0, 0};
+            bool have = false;
+            {
+                std::unique_lock<std::mutex> g(m);
+                if (stop) break;
+                if (!filled.empty()) {
+                    got = filled.front();
+                    filled.pop_front();
+                    have = true;
+                }
+            }
+            if (have) {
+                uint64_t ticket = 0;
+                Session::check(mkckks_upload_async(s.ctx(), jobs[got.second].d_dst, ring->slot(got.first), in_bytes, &ticket));
+                up_flight.emplace_back(ticket, got.first);
+                ++enq[jobs[got.second].chunk];
+                ++uploaded;
+                progress = true;
+            }
+            while (!up_flight.empty()) {  // uploads complete in ticket order
+                int done = 0;
+                Session::check(mkckks_copy_done(s.ctx(), up_flight.front().first, &done));
+                if (!done) break;
+                {
+                    std::lock_guard<std::mutex> g(m);
+                    free_slots.push_back(up_flight.front().second);
+                }
+                cv_free.notify_one();
+                up_flight.pop_front();
+                progress = true;
+                if (up_flight.empty() && uploaded == jobs.size()) tm.last_upload = now_ms() - t0;
+            }
+            // the next chunk in order whose uploads are all enqueued: everything below is asynchronous
+            if (computed < n_chunks && enq[computed] == n_clients * chunk_cnt(computed)) {
+                const size_t c = computed, cnt = chunk_cnt(c), b0 = chunk_b0[c];
+                uint64_t *base = chunk_base(c), *slot = base + n_pre * cnt * words, *sum = d_sum + b0 * words;
+                Session::check(mkckks_fence_uploads(s.ctx()));
+                if (n_pre)  // with clients already in the domain the re-encrypted sum is one more term of their EvalAdd
+                    Session::check(mkckks_reencrypt_sum_batch(s.ctx(), base, d_evk, n_plain ? slot : sum, (uint32_t)n_pre, (uint32_t)cnt, nl));
+                if (n_plain) {
+                    const uint64_t *terms = n_pre ? slot : slot + cnt * words;
+                    Session::check(mkckks_eval_sum_batch(s.ctx(), terms, sum, (uint32_t)(n_plain + (n_pre ? 1 : 0)), (uint32_t)cnt, nl));
+                }
+                uint64_t *outp;
+                if (rescale) {
+                    outp = d_out + b0 * owords;
+                    Session::check(mkckks_rescale_mult_const_batch(s.ctx(), sum, outp, (uint32_t)cnt, nl, operand));
+                } else {
+                    Session::check(mkckks_mult_const_batch(s.ctx(), sum, (uint32_t)cnt, nl, operand));
+                    outp = sum;
+                }
+                Session::check(mkckks_fence_compute(s.ctx()));
+                for (size_t i = 0; i < cnt; ++i) {
+                    uint64_t ticket = 0;
+                    Session::check(mkckks_download_async(s.ctx(), out_pin.slot((unsigned)(b0 + i)), outp + i * owords, out_bytes, &ticket));
+                    down_flight.emplace_back(ticket, b0 + i);
+                }
+                ++computed;
+                progress = true;
+            }
+            while (!down_flight.empty()) {
+                int done = 0;
+                Session::check(mkckks_copy_done(s.ctx(), down_flight.front().first, &done));
+                if (!done) break;
+                {
+                    std::lock_guard<std::mutex> g(m);
+                    to_write.push_back(down_flight.front().second);
+                }
+                cv_write.notify_one();
+                down_flight.pop_front();
+                ++downloaded;
+                progress = true;
+                if (downloaded == B) tm.last_download = now_ms() - t0;
+            }
+            if (!progress) {
+                std::unique_lock<std::mutex> g(m);
+                if (filled.empty() && !stop) cv_event.wait_for(g, std::chrono::microseconds(40));
+            }
+        }
+        bool stopped;
+        {
+            std::lock_guard<std::mutex> g(m);
+            stopped = stop;
+        }
+        // headers, then the residues of every input (the kernels above do no data-dependent addressing; a bad residue only
+        // makes bad numbers, and the output is withdrawn below before anyone can read it)
+        for (size_t j = 0; j < jobs.size() && !stopped; ++j) {
+            const Ciphertext mj = meta_of(jobs[j].hdr, s);
+            if (mj.nl != first.nl || mj.noise_deg != first.noise_deg || mj.scale != first.scale)
+                throw std::runtime_error("EvalAdd operands differ in level or scale");
+        }
+        uint64_t bad_total = 0;
+        for (size_t c = 0; c < n_chunks && !stopped; ++c) {
+            const size_t cnt = chunk_cnt(c);
+            uint64_t bad = 0;
+            if (n_pre) {
+                Session::check(mkckks_count_noncanonical(s.ctx(), chunk_base(c), (uint32_t)(n_pre * cnt), nl, &bad));
+                bad_total += bad;
+            }
+            if (n_plain) {
+                Session::check(mkckks_count_noncanonical(s.ctx(), chunk_base(c) + (n_pre + 1) * cnt * words, (uint32_t)(n_plain * cnt), nl, &bad));
+                bad_total += bad;
+            }
+        }
+        if (bad_total) throw std::runtime_error("ciphertext: residue not below its modulus");
+    } catch (...) {
+        main_err = std::current_exception();
+    }
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (main_err) stop = true;
+        writes_closed = true;
+    }
+    cv_free.notify_all();
+    cv_write.notify_all();
+    for (std::thread &t : pool) t.join();
+    if (main_err || err) {
+        mkckks_sync(s.ctx());       // nothing of this round may still be running when the buffers go away
+        ::unlink(path.c_str());
+        std::rethrow_exception(main_err ? main_err : err);
+    }
+    tm.round = now_ms() - t0;
+    tm.read_busy = read_busy;
+    tm.write_busy = write_busy;
+    agg.d_out = rescale ? d_out : d_sum;  // the aggregate as one array for the --back leg
+    return agg;
 }
 
 }  // namespace mkh

@@ -110,59 +110,36 @@ int main(int argc, char *argv[]) {
         uint64_t *d_back = nullptr, *d_back_evk = nullptr;
         std::unique_ptr<PinnedRing> ring;
         const unsigned threads = io_threads();
-        double t_in = 0, t_compute = 0, t_out = 0;
-        if (!items.empty()) {
+        if (!items.empty() && piped) {
+            RoundPlan plan;
+            plan.n_clients = n_clients;
+            plan.n_pre = n_pre;
+            plan.idx = &idx;
+            plan.items = &items;
+            plan.evks = evks.data();
+            plan.evk_words = evk_words;
+            plan.threads = threads;
+            RoundTimes tm;
+            agg = run_round_pipeline(s, plan, outputJson, output_file, ring, tm);
+            const double n_ct = (double)(n_clients * items.size());
+            std::cout << "[round] timing: " << n_clients << " clients x " << items.size() << " ciphertexts, chunks of " << tm.chunk
+                      << " indices, " << threads << " I/O threads: files to file " << tm.round << " ms -> " << n_ct / tm.round * 1e3
+                      << " ciphertexts/s (last upload done at " << tm.last_upload << " ms, last download at " << tm.last_download
+                      << " ms; reader threads busy " << tm.read_busy << " ms, writer threads " << tm.write_busy
+                      << " ms in total); once per process: index + buffers + key upload " << now_ms() - t_io0 - tm.round
+                      << " ms\n";
+        } else if (!items.empty()) {
             const size_t B = items.size();
             const size_t n_plain = n_clients - n_pre;
-            Ciphertext first;
-            uint64_t *d_all = nullptr, *d_slot = nullptr;
-            size_t words = 0, blk = 0;
-            if (piped) {
-                // shape of the round from the first container's header; every other one must carry the same payload size
-                BlobHeader h0;
-                const BlobRef &b0 = idx[0].blobs.at(blob_index(*items[0].blobs[0]));
-                if (b0.size < sizeof(BlobHeader)) throw std::runtime_error("ciphertext blob too short");
-                pread_all(idx[0].fd, &h0, sizeof h0, b0.offset);
-                first = meta_of(h0, s);
-                words = (size_t)2 * first.nl * N;
-                blk = B * words;
-                d_all = s.alloc<uint64_t>((n_clients + 1) * blk);
-                d_slot = d_all + n_pre * blk;
-                ring.reset(new PinnedRing(s, words * 8, std::max(2u, std::min<unsigned>(16u, (unsigned)(2 * threads)))));
-                std::vector<LoadJob> jobs;
-                jobs.reserve(n_clients * B);
-                for (size_t k = 0; k < n_clients; ++k)       // device layout as below: re-keyed clients, the sum slot, the others
-                    for (size_t b = 0; b < B; ++b) {
-                        const size_t bi = blob_index(*items[b].blobs[k]);
-                        uint64_t *dst = (k < n_pre ? d_all + k * blk : d_slot + (1 + (k - n_pre)) * blk) + b * words;
-                        jobs.push_back(LoadJob{idx[k].fd, idx[k].blobs.at(bi), dst, BlobHeader{}});
-                    }
-                load_ciphertexts(s, *ring, jobs, words * 8, threads);
-                for (const LoadJob &j : jobs) {
-                    const Ciphertext m = meta_of(j.hdr, s);
-                    if (m.nl != first.nl || m.noise_deg != first.noise_deg || m.scale != first.scale)
-                        throw std::runtime_error("EvalAdd operands differ in level or scale");
-                }
-                Session::check(mkckks_fence_uploads(s.ctx()));
-                uint64_t bad = 0, bad2 = 0;
-                if (n_pre) Session::check(mkckks_count_noncanonical(s.ctx(), d_all, (uint32_t)(n_pre * B), first.nl, &bad));
-                if (n_plain) Session::check(mkckks_count_noncanonical(s.ctx(), d_slot + blk, (uint32_t)(n_plain * B), first.nl, &bad2));
-                if (bad + bad2) throw std::runtime_error("ciphertext: residue not below its modulus");
-            } else {
-                std::vector<uint64_t> flat;  // [client in `order`][ct][2][nl][N]
-                first = gather_agg_inputs(items, n_clients, s, flat);
-                words = (size_t)2 * first.nl * N;
-                blk = B * words;
-                // device layout: [re-keyed clients][one slot for their re-encrypted sum][clients already in the domain]:
-                // the slot and what follows it are the terms of the final n-ary EvalAdd, no copy in between
-                d_all = s.alloc<uint64_t>((n_clients + 1) * blk);
-                d_slot = d_all + n_pre * blk;
-                if (n_pre) Session::check(mkckks_upload(s.ctx(), d_all, flat.data(), n_pre * blk * 8));
-                if (n_plain) Session::check(mkckks_upload(s.ctx(), d_slot + blk, flat.data() + n_pre * blk, n_plain * blk * 8));
-            }
+            std::vector<uint64_t> flat;  // [client in `order`][ct][2][nl][N]
+            const Ciphertext first = gather_agg_inputs(items, n_clients, s, flat);
+            const size_t words = (size_t)2 * first.nl * N, blk = B * words;
+            // device layout: [re-keyed clients][one slot for their re-encrypted sum][clients already in the domain]:
+            // the slot and what follows it are the terms of the final n-ary EvalAdd, no copy in between
+            uint64_t *d_all = s.alloc<uint64_t>((n_clients + 1) * blk), *d_slot = d_all + n_pre * blk;
+            if (n_pre) Session::check(mkckks_upload(s.ctx(), d_all, flat.data(), n_pre * blk * 8));
+            if (n_plain) Session::check(mkckks_upload(s.ctx(), d_slot + blk, flat.data() + n_pre * blk, n_plain * blk * 8));
             const uint32_t nl = first.nl;
-            t_in = now_ms() - t_io0;
-            const double t_c0 = now_ms();
             uint64_t *d_sum = d_slot;
             if (n_pre) {
                 uint64_t *d_evk = s.to_device(evks.data(), evks.size());
@@ -174,23 +151,7 @@ int main(int argc, char *argv[]) {
                 Session::check(mkckks_eval_sum_batch(s.ctx(), d_terms, d_sum, (uint32_t)(n_plain + (n_pre ? 1 : 0)),
                                                      (uint32_t)B, nl));
             }
-            if (piped) {
-                agg = scale_aggregate(s, B, d_sum, first, n_clients);
-                Session::check(mkckks_sync(s.ctx()));
-                t_compute = now_ms() - t_c0;
-                const double t_o0 = now_ms();
-                write_envelope_from_device(s, *ring, items, agg.d_out, agg.meta, outputJson, output_file, threads);
-                t_out = now_ms() - t_o0;
-            } else {
-                agg = finish_aggregate(s, items, d_sum, first, n_clients, outputJson);
-            }
-            if (piped) {
-                const double n_ct = (double)(n_clients * B), e2e = t_in + t_compute + t_out;
-                std::cout << "[round] timing: " << n_clients << " clients x " << B << " ciphertexts (" << words * 8 / 1048576.0
-                          << " MiB each), " << threads << " I/O threads: index+read+upload " << t_in << " ms, key upload+compute "
-                          << t_compute << " ms, download+write " << t_out << " ms -> " << n_ct / e2e * 1e3
-                          << " ciphertexts/s files to file (context and re-encryption keys loaded before)\n";
-            }
+            agg = finish_aggregate(s, items, d_sum, first, n_clients, outputJson);
         }
         if (!(piped && !items.empty()))
         write_envelope(outputJson, output_file, binary);

@@ -19,6 +19,7 @@
 // One host thread drives the context; the other threads only touch file descriptors and pinned memory.
 #pragma once
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -298,7 +299,7 @@ struct RoundPlan {
 };
 
 inline unsigned round_chunk(size_t B) {
-    unsigned c = 4;
+    unsigned c = 2;
     if (const char *e = std::getenv("MKCKKS_ROUND_CHUNK")) c = (unsigned)std::max(1, std::atoi(e));
     return (unsigned)std::min<size_t>(c, B);
 }
@@ -370,17 +371,45 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
     }
     const uint64_t blobs0 = head.size(), blob_size = sizeof(BlobHeader) + out_bytes;
     const BlobHeader out_hdr = header_of(res, N);
+    {   // process warm-up, the last part of the setup: copy streams, the workspace of one chunk and the first launch of every
+        // kernel of the round (the HIP runtime resolves a kernel when it is first launched: ~30 ms for this path), on
+        // whatever the fresh buffers hold -- none of the kernels addresses memory by data, and chunk 0 is overwritten below
+        uint64_t ticket = 0;
+        Session::check(mkckks_upload_async(s.ctx(), d_all, ring->slot(0), in_bytes, &ticket));  // full-size copies: the first large one of a direction costs ~8 ms
+        Session::check(mkckks_fence_uploads(s.ctx()));
+        const size_t cnt = std::min<size_t>(Bc, B);
+        uint64_t *slot = d_all + n_pre * cnt * words;
+        if (n_pre) Session::check(mkckks_reencrypt_sum_batch(s.ctx(), d_all, d_evk, n_plain ? slot : d_sum, (uint32_t)n_pre, (uint32_t)cnt, nl));
+        if (n_plain)
+            Session::check(mkckks_eval_sum_batch(s.ctx(), n_pre ? slot : slot + cnt * words, d_sum, (uint32_t)(n_plain + (n_pre ? 1 : 0)), (uint32_t)cnt, nl));
+        if (rescale) Session::check(mkckks_rescale_mult_const_batch(s.ctx(), d_sum, d_out, (uint32_t)cnt, nl, 1.0 / (double)n_clients));
+        else Session::check(mkckks_mult_const_batch(s.ctx(), d_sum, (uint32_t)cnt, nl, 1.0 / (double)n_clients));
+        Session::check(mkckks_fence_compute(s.ctx()));
+        Session::check(mkckks_download_async(s.ctx(), out_pin.slot(0), rescale ? d_out : d_sum, out_bytes, &ticket));
+        Session::check(mkckks_copy_wait(s.ctx(), ticket));
+        Session::check(mkckks_sync(s.ctx()));
+    }
     tm.setup = now_ms() - t_setup0;
 
     const double t0 = now_ms();
-    const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    const int fd = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) throw std::runtime_error("cannot write " + path);
     struct Closer {
         int fd;
         ~Closer() { ::close(fd); }
     } closer{fd};
-    if (::ftruncate(fd, (off_t)(blobs0 + B * (8 + blob_size))) != 0) throw std::runtime_error("cannot size " + path);
-    pwrite_all(fd, head.data(), head.size(), 0);
+    // The output goes through a shared mapping of the file: write() holds the inode lock, so parallel pwrite()s into ONE
+    // tmpfs file run one after the other (~3 GB/s in total, measured); copies into the mapping do not.  The pages are
+    // reserved first (fallocate, by the first writer thread, while the uploads run): no SIGBUS for a full file system later.
+    const size_t file_bytes = blobs0 + B * (8 + blob_size);
+    if (::ftruncate(fd, (off_t)file_bytes) != 0) throw std::runtime_error("cannot size " + path);
+    char *const map = static_cast<char *>(::mmap(nullptr, file_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0));
+    if (map == MAP_FAILED) throw std::runtime_error("cannot map " + path);
+    struct Unmapper {
+        char *p;
+        size_t n;
+        ~Unmapper() { ::munmap(p, n); }
+    } unmapper{map, file_bytes};
 
     // jobs in chunk order: chunk, client, index within the chunk
     struct Job {
@@ -389,6 +418,7 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
         uint64_t *d_dst;
         BlobHeader hdr;
         unsigned chunk;
+        double t_read0 = 0, t_read1 = 0, t_enq = 0, t_done = 0;  // MKCKKS_IO_TRACE
     };
     std::vector<Job> jobs;
     jobs.reserve(n_clients * B);
@@ -403,7 +433,7 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
             for (size_t i = 0; i < cnt; ++i) {
                 const size_t b = chunk_b0[c] + i, bi = blob_index(*items[b].blobs[k]);
                 const size_t slot_k = k < n_pre ? k : k + 1;  // position n_pre is the sum slot
-                jobs.push_back(Job{idx[k].fd, idx[k].blobs.at(bi), chunk_base(c) + (slot_k * cnt + i) * words, BlobHeader{}, (unsigned)c});
+                jobs.push_back(Job{idx[k].fd, idx[k].blobs.at(bi), chunk_base(c) + (slot_k * cnt + i) * words, BlobHeader{}, (unsigned)c, 0, 0, 0, 0});
             }
     }
 
@@ -411,7 +441,7 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
     std::condition_variable cv_free, cv_event, cv_write;
     std::deque<unsigned> free_slots;
     std::deque<std::pair<unsigned, size_t>> filled;  // (slot, job)
-    std::deque<size_t> to_write;                      // output index b, downloaded
+    std::deque<size_t> to_write;                      // (output index b, part) of a downloaded ciphertext
     for (unsigned i = 0; i < ring->count(); ++i) free_slots.push_back(i);
     std::atomic<size_t> next{0};
     std::exception_ptr err;
@@ -443,6 +473,8 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
                 pread_all(job.fd, &job.hdr, sizeof(BlobHeader), job.blob.offset);
                 pread_all(job.fd, ring->slot(slot), in_bytes, job.blob.offset + sizeof(BlobHeader));
                 busy += now_ms() - tb;
+                job.t_read0 = tb - t0;
+                job.t_read1 = now_ms() - t0;
                 {
                     std::lock_guard<std::mutex> g(m);
                     filled.emplace_back(slot, j);
@@ -455,26 +487,44 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
         std::lock_guard<std::mutex> g(m);
         read_busy += busy;
     };
+    // a downloaded ciphertext is written in WRITE_PARTS pieces by different threads: the last chunk's write is the tail of
+    // the round.  The first writer reserves the file's pages (fallocate: tmpfs allocates and clears them) while the uploads
+    // run, so that the writes proper are plain copies.
+    constexpr unsigned WRITE_PARTS = 4;
+    std::atomic<bool> reserve_taken{false};
+    bool reserved = false;
     auto writer = [&] {
         double busy = 0;
         try {
+            if (!reserve_taken.exchange(true)) {
+                const int rc = ::posix_fallocate(fd, 0, (off_t)file_bytes);
+                if (rc != 0) throw std::runtime_error("cannot reserve " + path + ": " + std::strerror(rc));
+                std::memcpy(map, head.data(), head.size());
+                {
+                    std::lock_guard<std::mutex> g(m);
+                    reserved = true;
+                }
+                cv_write.notify_all();
+            }
             for (;;) {
-                size_t b;
+                size_t w;
                 {
                     std::unique_lock<std::mutex> g(m);
-                    cv_write.wait(g, [&] { return stop || writes_closed || !to_write.empty(); });
+                    cv_write.wait(g, [&] { return stop || (reserved && (writes_closed || !to_write.empty())); });
                     if (stop) return;
                     if (to_write.empty()) break;  // closed and drained
-                    b = to_write.front();
+                    w = to_write.front();
                     to_write.pop_front();
                 }
                 const double tb = now_ms();
-                const uint64_t at = blobs0 + b * (8 + blob_size);
-                char pre[8 + sizeof(BlobHeader)];
-                std::memcpy(pre, &blob_size, 8);
-                std::memcpy(pre + 8, &out_hdr, sizeof out_hdr);
-                pwrite_all(fd, pre, sizeof pre, at);
-                pwrite_all(fd, out_pin.slot((unsigned)b), out_bytes, at + sizeof pre);
+                const size_t b = w / WRITE_PARTS, part = w % WRITE_PARTS;
+                char *at = map + blobs0 + b * (8 + blob_size);
+                if (part == 0) {
+                    std::memcpy(at, &blob_size, 8);
+                    std::memcpy(at + 8, &out_hdr, sizeof out_hdr);
+                }
+                const size_t lo = out_bytes * part / WRITE_PARTS, hi = out_bytes * (part + 1) / WRITE_PARTS;
+                std::memcpy(at + 8 + sizeof out_hdr + lo, out_pin.slot((unsigned)b) + lo, hi - lo);
                 busy += now_ms() - tb;
             }
         } catch (...) {
@@ -492,6 +542,9 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
     std::exception_ptr main_err;
     try {
         std::deque<std::pair<uint64_t, unsigned>> up_flight;   // (ticket, ring slot)
+        std::deque<size_t> up_jobs;                            // jobs of up_flight, for the trace
+        std::vector<std::pair<double, double>> chunk_enq(n_chunks);
+        double call_ms[6] = {0, 0, 0, 0, 0, 0};  // chunk 0's calls, for the trace
         std::deque<std::pair<uint64_t, size_t>> down_flight;   // (ticket, output index)
         std::vector<size_t> enq(n_chunks, 0);
         size_t uploaded = 0, computed = 0, downloaded = 0;
@@ -513,6 +566,8 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
                 uint64_t ticket = 0;
                 Session::check(mkckks_upload_async(s.ctx(), jobs[got.second].d_dst, ring->slot(got.first), in_bytes, &ticket));
                 up_flight.emplace_back(ticket, got.first);
+                up_jobs.push_back(got.second);
+                jobs[got.second].t_enq = now_ms() - t0;
                 ++enq[jobs[got.second].chunk];
                 ++uploaded;
                 progress = true;
@@ -527,20 +582,30 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
                 }
                 cv_free.notify_one();
                 up_flight.pop_front();
+                jobs[up_jobs.front()].t_done = now_ms() - t0;
+                up_jobs.pop_front();
                 progress = true;
                 if (up_flight.empty() && uploaded == jobs.size()) tm.last_upload = now_ms() - t0;
             }
             // the next chunk in order whose uploads are all enqueued: everything below is asynchronous
             if (computed < n_chunks && enq[computed] == n_clients * chunk_cnt(computed)) {
                 const size_t c = computed, cnt = chunk_cnt(c), b0 = chunk_b0[c];
+                chunk_enq[c].first = now_ms() - t0;
                 uint64_t *base = chunk_base(c), *slot = base + n_pre * cnt * words, *sum = d_sum + b0 * words;
+                double tc = now_ms();
+                auto lap = [&](int i) {
+                    if (c == 0) call_ms[i] = now_ms() - tc;
+                    tc = now_ms();
+                };
                 Session::check(mkckks_fence_uploads(s.ctx()));
+                lap(0);
                 if (n_pre)  // with clients already in the domain the re-encrypted sum is one more term of their EvalAdd
                     Session::check(mkckks_reencrypt_sum_batch(s.ctx(), base, d_evk, n_plain ? slot : sum, (uint32_t)n_pre, (uint32_t)cnt, nl));
                 if (n_plain) {
                     const uint64_t *terms = n_pre ? slot : slot + cnt * words;
                     Session::check(mkckks_eval_sum_batch(s.ctx(), terms, sum, (uint32_t)(n_plain + (n_pre ? 1 : 0)), (uint32_t)cnt, nl));
                 }
+                lap(1);
                 uint64_t *outp;
                 if (rescale) {
                     outp = d_out + b0 * owords;
@@ -549,12 +614,16 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
                     Session::check(mkckks_mult_const_batch(s.ctx(), sum, (uint32_t)cnt, nl, operand));
                     outp = sum;
                 }
+                lap(2);
                 Session::check(mkckks_fence_compute(s.ctx()));
+                lap(3);
                 for (size_t i = 0; i < cnt; ++i) {
                     uint64_t ticket = 0;
                     Session::check(mkckks_download_async(s.ctx(), out_pin.slot((unsigned)(b0 + i)), outp + i * owords, out_bytes, &ticket));
                     down_flight.emplace_back(ticket, b0 + i);
                 }
+                lap(4);
+                chunk_enq[c].second = now_ms() - t0;
                 ++computed;
                 progress = true;
             }
@@ -564,9 +633,9 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
                 if (!done) break;
                 {
                     std::lock_guard<std::mutex> g(m);
-                    to_write.push_back(down_flight.front().second);
+                    for (unsigned part = 0; part < WRITE_PARTS; ++part) to_write.push_back(down_flight.front().second * WRITE_PARTS + part);
                 }
-                cv_write.notify_one();
+                cv_write.notify_all();
                 down_flight.pop_front();
                 ++downloaded;
                 progress = true;
@@ -581,6 +650,18 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
         {
             std::lock_guard<std::mutex> g(m);
             stopped = stop;
+        }
+        if (const char *tr = std::getenv("MKCKKS_IO_TRACE")) {
+            if (FILE *f = std::fopen(tr, "w")) {
+                std::fprintf(f, "# job chunk read_start read_end upload_enqueued upload_seen_done (ms since the round started)\n");
+                for (size_t j = 0; j < jobs.size(); ++j)
+                    std::fprintf(f, "%zu %u %.3f %.3f %.3f %.3f\n", j, jobs[j].chunk, jobs[j].t_read0, jobs[j].t_read1, jobs[j].t_enq, jobs[j].t_done);
+                std::fprintf(f, "# chunk compute_enqueue_start compute_enqueue_end\n");
+                for (size_t c = 0; c < n_chunks; ++c) std::fprintf(f, "c%zu %.3f %.3f\n", c, chunk_enq[c].first, chunk_enq[c].second);
+                std::fprintf(f, "# chunk 0 calls: fence_uploads %.3f, reencrypt_sum(+eval_sum) %.3f, scale %.3f, fence_compute %.3f, download_async %.3f ms\n",
+                             call_ms[0], call_ms[1], call_ms[2], call_ms[3], call_ms[4]);
+                std::fclose(f);
+            }
         }
         // headers, then the residues of every input (the kernels above do no data-dependent addressing; a bad residue only
         // makes bad numbers, and the output is withdrawn below before anyone can read it)

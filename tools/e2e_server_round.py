@@ -5,15 +5,19 @@ ciphertexts), files in tmpfs -> file in tmpfs.
   genCC (RingDim 65536, depth 10, 50-bit scaling) -> keyGen x 9 -> encryptModelWeights x 8 (MKWS envelopes, 16 ciphertexts
   of 12.6 MB each) -> REkeyGen x 8 (every client into the ninth key's domain, so all 8 x 16 ciphertexts are re-encrypted as
   in bench.py's step) -> serverRound, once per arm:
-    pipelined, MKCKKS_IO_THREADS = 1, 2, 4, 8, 16     (host/iopipe.hpp)
+    pipelined, MKCKKS_IO_THREADS = 1, 2, 4, 8, 12     (host/iopipe.hpp; chunks of 2 ciphertext indices)
+    pipelined, 8 threads, MKCKKS_ROUND_CHUNK = 1, 3, 6, 18
     MKCKKS_SYNC_IO=1                                   (read_envelope / decode_ct / mkckks_upload, the r02 path)
-Every arm's aggregate file must have the same bytes.  Prints serverRound's "[round] timing" line (index+read+upload,
-key upload+compute, download+write; context + key loading excluded) and the whole process's wall time per arm.
+Every arm's aggregate file must have the same bytes.  Per arm, over --reps runs: serverRound's own "files to file" time
+(first read -> last byte written, buffers / keys / kernels resident: what a server process pays per round) as
+min / median / max, and the whole process's wall time (context tables, JSON keys, pinned buffers, HIP start-up: paid once
+per process).  encryptModelWeights packs the layer's mean and std_dev as two more ciphertexts: 18 per client.
 usage: python tools/e2e_server_round.py [--dir /dev/shm/mkckks_e2e] [--clients 8] [--cts 16] [--keep]"""
 import argparse
 import hashlib
 import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -54,6 +58,8 @@ def main():
     ap.add_argument("--clients", type=int, default=8)
     ap.add_argument("--cts", type=int, default=16)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--arms", default="", help="instead of the default arms: 'K=V,K=V;K=V;...' (environment of serverRound per arm)")
     args = ap.parse_args()
     d = args.dir
     shutil.rmtree(d, ignore_errors=True)
@@ -85,26 +91,40 @@ def main():
         print(f"# serverRound at the C3 shape: {C} clients x {B} ciphertexts, N=2^16, L=12, dnum=3; files in {d}")
         print(f"# input: {enc_mb:.1f} MiB of ciphertexts + {rk_mb:.1f} MiB re-encryption key per client; preparing them "
               f"(keyGen/encrypt/REkeyGen, {C} clients) took {t_prep:.1f} s")
-        arms = [(f"pipelined, {t:2d} I/O threads", {"MKCKKS_IO_THREADS": str(t)}) for t in (1, 2, 4, 8, 16)]
+        arms = [(f"pipelined, {t:2d} I/O threads", {"MKCKKS_IO_THREADS": str(t)}) for t in (1, 2, 4, 8, 12)]
+        arms += [(f"pipelined, 8 threads, chunk {c:2d}", {"MKCKKS_IO_THREADS": "8", "MKCKKS_ROUND_CHUNK": str(c)}) for c in (1, 3, 6, 18)]
         arms.append(("synchronous (MKCKKS_SYNC_IO=1)", {"MKCKKS_SYNC_IO": "1"}))
+        if args.arms:
+            arms = [(a, dict(kv.split("=", 1) for kv in a.split(",") if kv)) for a in args.arms.split(";")]
         digest = None
+        n_total = None
+        print(f"{'arm':34s} {'round ms: min / median / max':>30s} {'ct/s (median)':>14s} {'process wall s':>15s}   last line of the median run")
         for name, env in arms:
-            best = None
-            for rep in range(2):  # second run: page cache / tmpfs pages warm on both sides
+            runs = []
+            for rep in range(args.reps):
                 out = p("agg.mkws")
                 if os.path.exists(out):
                     os.remove(out)
                 r, dt = run("serverRound", p("CC.json"), out, *pairs, env=env)
                 line = [ln for ln in r.stdout.splitlines() if "[round] timing:" in ln]
-                if best is None or dt < best[0]:
-                    best = (dt, line[0] if line else "(no timing line: synchronous path)")
+                ms = None
+                if line:
+                    m = re.search(r"(\d+) clients x (\d+) ciphertexts.*files to file ([0-9.]+) ms", line[0])
+                    n_total, ms = int(m.group(1)) * int(m.group(2)), float(m.group(3))
+                runs.append((ms if ms is not None else dt * 1e3, dt, line[0] if line else ""))
                 h = sha(out)
                 if digest is None:
                     digest = h
                 if h != digest:
                     raise SystemExit(f"arm '{name}' wrote different bytes")
-            print(f"{name:32s} process wall {best[0]:6.2f} s = {C * B / best[0]:7.0f} ct/s incl. context + key loading")
-            print(f"    {best[1]}")
+            runs.sort()
+            med = runs[len(runs) // 2]
+            walls = sorted(r[1] for r in runs)
+            if med[2]:
+                print(f"{name:34s} {runs[0][0]:9.1f} / {med[0]:6.1f} / {runs[-1][0]:6.1f} {n_total / med[0] * 1e3:14.0f} {walls[len(walls) // 2]:15.2f}")
+                print("    " + med[2].strip())
+            else:
+                print(f"{name:34s} {'(whole process:)':>30s} {(n_total or C * B) / walls[len(walls) // 2]:14.0f} {walls[len(walls) // 2]:15.2f}")
         print(f"# every arm wrote the same aggregate: sha256 {digest[:16]}..., {os.path.getsize(p('agg.mkws')) / 1048576.0:.1f} MiB")
     finally:
         if not args.keep:

@@ -244,6 +244,9 @@ class Context:
 
     def close(self):
         if self._h:
+            for p in list(getattr(self, "_pinned", {}).values()):  # pinned buffers the caller did not give back
+                self._L.mkckks_host_free(self._h, p)
+            self._pinned = {}
             self._L.mkckks_ctx_destroy(self._h)
             self._h = None
 

@@ -836,6 +836,8 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTable
             }
             x[k] = reduce_cols4(acc, lc);
             if (AR == AR_FP) x[k] = dbits(fp_reduce((double)x[k], lc.qd, lc.qinv));
+            asm volatile("" : "+v"(x[k]));  // as above: keep the arithmetic beside its loads (111 spilled registers otherwise)
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     stm.mark<1>();
@@ -926,23 +928,8 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_psum(ConvIo io, Ntt
     uint32_t grp, jt;
     group_member(blockIdx.x, groups, io.nsel, T.cu_affine, grp, jt);
     jt = nth_set_bit(io.target_mask, jt);
-#if MK_TILE_MAJOR == 1  // experiment: XCD = item % 8 instead of tile % 8 (every XCD sees every column tile, i.e. every 128-byte phase of a row)
-    const uint32_t tile = grp / io.items, item = grp % io.items;
-#elif MK_TILE_MAJOR == 2  // experiment: XCD = item % 8 AND the tiles of an item consecutive in its queue: the ~18 source tiles an XCD
-    // works on at any moment cover all 16 column phases (128-byte offsets inside a 2-KiB row) instead of one or two
-    uint32_t item, tile;
-    if (groups % 8 == 0 && io.items % 8 == 0) {
-        const uint32_t u = grp / 8;
-        tile = u % tiles;
-        item = (u / tiles) * 8 + grp % 8;
-    } else {
-        item = grp / tiles;
-        tile = grp % tiles;
-    }
-#else
     uint32_t item, tile;
     conv_item_tile(grp, groups, io.items, tiles, item, tile);
-#endif
     const uint32_t id = cv.dst_id[jt];
     const LimbConst lc = T.limb[id];
     if ((lc.fp != 0) != (AR == AR_FP)) return;  // never: the host selects the targets of this instance's class
@@ -1002,6 +989,8 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_psum(ConvIo io, Ntt
                     mac_cols4(acc, a0, a1, h0[i], h1[i]);
                 }
                 x[kk] = reduce_cols4(acc, lc);
+                asm volatile("" : "+v"(x[kk]));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }

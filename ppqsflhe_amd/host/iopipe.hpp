@@ -293,7 +293,8 @@ struct RoundPlan {
     size_t n_clients = 0, n_pre = 0;          // clients in `order`; the first n_pre carry a re-encryption key
     const std::vector<EnvelopeIndex> *idx = nullptr;
     const std::vector<AggItem> *items = nullptr;
-    const uint64_t *evks = nullptr;           // host [n_pre][beta][2][D][N]
+    std::vector<const uint64_t *> evks;       // host, one [beta][2][D][N] per re-keyed client
+    const std::vector<std::string> *evk_names = nullptr;  // their file names (what the cache compares)
     size_t evk_words = 0;
     unsigned threads = 4;
 };
@@ -304,10 +305,55 @@ inline unsigned round_chunk(size_t B) {
     return (unsigned)std::min<size_t>(c, B);
 }
 
+// What a server process keeps from one round to the next (serverRound --rounds): device arrays and pinned buffers grown
+// on demand, the re-encryption keys that are resident in HBM (by file name, in order), and whether the kernels of the
+// round's shape have been launched once.  A one-shot run simply has a cache that lives for one round.
+class RoundCache {
+public:
+    explicit RoundCache(Session &s) : s_(s) {}
+    ~RoundCache() {
+        for (Slot *b : {&all, &sum, &out, &evk, &back, &back_evk})
+            if (b->p) mkckks_dev_free(s_.ctx(), b->p);
+    }
+    RoundCache(const RoundCache &) = delete;
+    RoundCache &operator=(const RoundCache &) = delete;
+    struct Slot {
+        uint64_t *p = nullptr;
+        size_t words = 0;
+    };
+    uint64_t *grow(Slot &b, size_t words) {
+        if (words > b.words) {
+            Session::check(mkckks_sync(s_.ctx()));
+            if (b.p) Session::check(mkckks_dev_free(s_.ctx(), b.p));
+            b.p = nullptr;
+            b.words = 0;
+            void *p = nullptr;
+            Session::check(mkckks_dev_alloc(s_.ctx(), words * 8, &p));
+            b.p = static_cast<uint64_t *>(p);
+            b.words = words;
+        }
+        return b.p;
+    }
+    PinnedRing &pinned(std::unique_ptr<PinnedRing> &r, size_t slot_bytes, unsigned slots) {
+        if (!r || r->slot_bytes() < slot_bytes || r->count() < slots) {
+            r.reset();
+            r.reset(new PinnedRing(s_, slot_bytes, slots));
+        }
+        return *r;
+    }
+    Slot all, sum, out, evk, back, back_evk;
+    std::vector<std::string> evk_names;  // keys resident in evk.p, in order
+    std::unique_ptr<PinnedRing> ring, out_pin;
+    std::string warm_shape;              // "<nl>/<chunk>/<n_pre>/<n_plain>/<rescale>" the kernels were launched with
+
+private:
+    Session &s_;
+};
+
 // aggregate of all clients' ciphertexts, scaled by 1/n, left in HBM ([B][2][meta.nl][N], for the --back leg) and written
 // to `path` as an MKWS envelope -- the same bytes as the synchronous path (tests/test_cli_hosts.py)
-inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc, const std::string &path,
-                                    std::unique_ptr<PinnedRing> &ring, RoundTimes &tm) {
+inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc, const std::string &path, RoundCache &cache,
+                                    RoundTimes &tm) {
     const double t_setup0 = now_ms();
     const std::vector<AggItem> &items = *plan.items;
     const std::vector<EnvelopeIndex> &idx = *plan.idx;
@@ -336,12 +382,22 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
     const size_t owords = (size_t)2 * res.nl * N, out_bytes = owords * 8;
     // device: per chunk of cnt indices [re-keyed clients][slot for their sum][clients already in the domain] x [cnt], so that
     // every chunk is what mkckks_reencrypt_sum_batch / mkckks_eval_sum_batch take; sums and outputs [B]
-    uint64_t *d_all = s.alloc<uint64_t>((n_clients + 1) * B * words);
-    uint64_t *d_sum = s.alloc<uint64_t>(B * words);  // sums over all clients, [B]
-    uint64_t *d_out = rescale ? s.alloc<uint64_t>(B * owords) : nullptr;
-    uint64_t *d_evk = n_pre ? s.to_device(plan.evks, n_pre * plan.evk_words) : nullptr;
-    ring.reset(new PinnedRing(s, in_bytes, std::max(4u, std::min<unsigned>(16u, 2 * plan.threads))));
-    PinnedRing out_pin(s, out_bytes, (unsigned)B);
+    uint64_t *d_all = cache.grow(cache.all, (n_clients + 1) * B * words);
+    uint64_t *d_sum = cache.grow(cache.sum, B * words);  // sums over all clients, [B]
+    uint64_t *d_out = rescale ? cache.grow(cache.out, B * owords) : nullptr;
+    uint64_t *d_evk = nullptr;
+    if (n_pre) {  // keys that are already resident (same files, same order) are not uploaded again
+        d_evk = cache.grow(cache.evk, n_pre * plan.evk_words);
+        if (cache.evk_names != *plan.evk_names) {
+            cache.evk_names.clear();
+            for (size_t k = 0; k < n_pre; ++k)
+                Session::check(mkckks_upload(s.ctx(), d_evk + k * plan.evk_words, plan.evks[k], plan.evk_words * 8));
+            cache.evk_names = *plan.evk_names;
+        }
+    }
+    std::unique_ptr<PinnedRing> &ring = cache.ring;
+    cache.pinned(cache.ring, in_bytes, std::max(4u, std::min<unsigned>(16u, 2 * plan.threads)));
+    PinnedRing &out_pin = cache.pinned(cache.out_pin, out_bytes, (unsigned)B);
     // output file: skeleton with "@<item>" fields, sized in advance, blobs written at fixed offsets
     for (size_t b = 0; b < B; ++b) {
         Json &lay = doc["weights_summary"].a[items[b].out_layer];
@@ -371,7 +427,9 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
     }
     const uint64_t blobs0 = head.size(), blob_size = sizeof(BlobHeader) + out_bytes;
     const BlobHeader out_hdr = header_of(res, N);
-    {   // process warm-up, the last part of the setup: copy streams, the workspace of one chunk and the first launch of every
+    const std::string shape = std::to_string(nl) + "/" + std::to_string(Bc) + "/" + std::to_string(n_pre) + "/" +
+                              std::to_string(n_plain) + "/" + std::to_string((int)rescale);
+    if (cache.warm_shape != shape) {   // process warm-up, the last part of the setup: copy streams, the workspace of one chunk and the first launch of every
         // kernel of the round (the HIP runtime resolves a kernel when it is first launched: ~30 ms for this path), on
         // whatever the fresh buffers hold -- none of the kernels addresses memory by data, and chunk 0 is overwritten below
         uint64_t ticket = 0;
@@ -388,6 +446,7 @@ inline AggResult run_round_pipeline(Session &s, const RoundPlan &plan, Json doc,
         Session::check(mkckks_download_async(s.ctx(), out_pin.slot(0), rescale ? d_out : d_sum, out_bytes, &ticket));
         Session::check(mkckks_copy_wait(s.ctx(), ticket));
         Session::check(mkckks_sync(s.ctx()));
+        cache.warm_shape = shape;
     }
     tm.setup = now_ms() - t_setup0;
 

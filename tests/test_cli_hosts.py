@@ -426,6 +426,22 @@ def test_server_round_io_pipeline_writes_the_same_bytes(tmp_path):
     rd = ok(run("serverRound", cc, tmp_path / "aggD.mkws", *args, env={"MKCKKS_SYNC_IO": "1"}))
     assert open(tmp_path / "aggC.mkws", "rb").read() == open(tmp_path / "aggD.mkws", "rb").read()
     assert "[round] timing:" in rc.stdout and rd.returncode == 0
+    # three rounds in ONE process (serverRound <cc> --rounds <file>; the loop of orchestration/run.sh:37-43): context, keys
+    # (by file name), device arrays, pinned buffers and resolved kernels stay; every round writes the bytes of its one-shot run
+    rounds = tmp_path / "rounds.txt"
+    rounds.write_text(
+        " ".join(map(str, [tmp_path / "r1.mkws", "-", tmp_path / f"enc{target}.mkws", *args, "--back", tmp_path / "rkback0",
+                           tmp_path / "r1back.mkws"])) + "\n# a comment line\n\n"
+        + " ".join(map(str, [tmp_path / "r2.mkws", *args])) + "\n"
+        + " ".join(map(str, [tmp_path / "r3.mkws", "-", tmp_path / f"enc{target}.mkws", *args])) + "\n")
+    rr = ok(run("serverRound", cc, "--rounds", rounds))
+    assert "[round] 3 rounds, " in rr.stdout and rr.stdout.count("[round] timing:") == 3
+    same = lambda a, b: open(tmp_path / a, "rb").read() == open(tmp_path / b, "rb").read()  # noqa: E731
+    assert same("r1.mkws", "aggB.mkws") and same("r1back.mkws", "backB.mkws")
+    assert same("r2.mkws", "aggC.mkws") and same("r3.mkws", "aggB.mkws")
+    rounds.write_text(f"{tmp_path / 'x.mkws'} {tmp_path / 'rk0'}\n")  # a key without its ciphertext file
+    r = run("serverRound", cc, "--rounds", rounds)
+    assert r.returncode == 1 and "malformed round" in r.stderr
     # a residue that is not below its modulus: both paths refuse the file (the pipelined one after the device-side check)
     raw = bytearray(open(tmp_path / "enc0.mkws", "rb").read())
     skel_len = int.from_bytes(raw[8:16], "little")

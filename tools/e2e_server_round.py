@@ -11,7 +11,8 @@ ciphertexts), files in tmpfs -> file in tmpfs.
 Every arm's aggregate file must have the same bytes.  Per arm, over --reps runs: serverRound's own "files to file" time
 (first read -> last byte written, buffers / keys / kernels resident: what a server process pays per round) as
 min / median / max, and the whole process's wall time (context tables, JSON keys, pinned buffers, HIP start-up: paid once
-per process).  encryptModelWeights packs the layer's mean and std_dev as two more ciphertexts: 18 per client.
+per process).  Last: `serverRound --rounds` with 10 and 40 rounds over the same inputs in ONE process, timed from outside
+(whole process) and per round (wall).  encryptModelWeights packs the layer's mean and std_dev as two more ciphertexts: 18 per client.
 usage: python tools/e2e_server_round.py [--dir /dev/shm/mkckks_e2e] [--clients 8] [--cts 16] [--keep]"""
 import argparse
 import hashlib
@@ -59,6 +60,7 @@ def main():
     ap.add_argument("--cts", type=int, default=16)
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--rounds", type=int, nargs="*", default=[10, 40], help="rounds per process for the --rounds legs")
     ap.add_argument("--arms", default="", help="instead of the default arms: 'K=V,K=V;K=V;...' (environment of serverRound per arm)")
     args = ap.parse_args()
     d = args.dir
@@ -125,6 +127,21 @@ def main():
                 print("    " + med[2].strip())
             else:
                 print(f"{name:34s} {'(whole process:)':>30s} {(n_total or C * B) / walls[len(walls) // 2]:14.0f} {walls[len(walls) // 2]:15.2f}")
+        # one process, many rounds (serverRound --rounds): context, keys, buffers and resolved kernels stay
+        for n_rounds in args.rounds:
+            with open(p("rounds.txt"), "w") as f:
+                for r in range(n_rounds):
+                    f.write(" ".join([p(f"agg_r{r}.mkws"), *pairs]) + "\n")
+            r, dt = run("serverRound", p("CC.json"), "--rounds", p("rounds.txt"), env={"MKCKKS_IO_THREADS": "8"})
+            per = [float(m) for m in re.findall(r"round \d+ of \d+: ([0-9.]+) ms wall", r.stdout)]
+            last = [ln for ln in r.stdout.splitlines() if " rounds, " in ln][-1]
+            for k in range(n_rounds):
+                if sha(p(f"agg_r{k}.mkws")) != digest:
+                    raise SystemExit(f"round {k} of the {n_rounds}-round process wrote different bytes")
+                os.remove(p(f"agg_r{k}.mkws"))
+            print(f"one process, {n_rounds:3d} rounds (8 I/O threads): whole process {dt:6.2f} s = {n_rounds * n_total / dt:6.0f} ct/s; per round "
+                  f"wall ms: first {per[0]:.1f}, then min {min(per[1:]):.1f} / median {sorted(per[1:])[len(per[1:]) // 2]:.1f} / max {max(per[1:]):.1f}")
+            print("    " + last.strip())
         print(f"# every arm wrote the same aggregate: sha256 {digest[:16]}..., {os.path.getsize(p('agg.mkws')) / 1048576.0:.1f} MiB")
     finally:
         if not args.keep:

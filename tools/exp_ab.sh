@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B: bash tools/exp_ab.sh <tag> "<env assignments for arm 1>" "<arm 2>" ...   (arm "base" = libmkckks_base.so)
+# same-box A/B: bash tools/exp_ab.sh <tag> "<env assignments for arm 1>" "<arm 2>" ...   (arm "base" = ppqsflhe_amd/libmkckks_base.so, a side build: make -C ppqsflhe_amd/csrc OUT=../libmkckks_base.so)
 # every arm: bench.py --steps 20 --warmup 3 --no-cpu, arms interleaved twice
 tag=$1; shift
 out=gpurun_out/${tag}_ab.txt

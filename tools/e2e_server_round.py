@@ -77,9 +77,11 @@ def main():
         t_prep = time.perf_counter()
         run("keyGen", p("CC.json"), p("pkT"), p("skT"))
         pairs = []
+        mean = np.zeros(B * 32768)
         for c in range(C):
             run("keyGen", p("CC.json"), p(f"pk{c}"), p(f"sk{c}"))
             vals = rng.uniform(-0.5, 0.5, B * 32768)
+            mean += vals / C
             with open(p(f"w{c}.json"), "w") as f:
                 json.dump({"weights_summary": [{"layer": "dense", "shape": [len(vals)], "mean": float(vals.mean()),
                                                 "std_dev": float(vals.std()), "values": vals.tolist()}]}, f)
@@ -142,6 +144,14 @@ def main():
             print(f"one process, {n_rounds:3d} rounds (8 I/O threads): whole process {dt:6.2f} s = {n_rounds * n_total / dt:6.0f} ct/s; per round "
                   f"wall ms: first {per[0]:.1f}, then min {min(per[1:]):.1f} / median {sorted(per[1:])[len(per[1:]) // 2]:.1f} / max {max(per[1:]):.1f}")
             print("    " + last.strip())
+        # the aggregate, decrypted under the target key, is the plaintext mean (the size-independent check of the whole chain
+        # at this shape: encode, encrypt, 8 x 18 re-encryptions, sum, rescale * 1/8, decrypt, decode)
+        run("decryptModelWeights", p("CC.json"), p("skT"), p("agg.mkws"), p("dec.json"))
+        dec = np.array(json.load(open(p("dec.json")))["weights_summary"][0]["values"])
+        err = float(np.abs(dec - mean).max())
+        if dec.size != mean.size or not err < 2.0 ** -25:
+            raise SystemExit(f"decrypted aggregate differs from the plaintext mean: {dec.size} values, max error {err:g}")
+        print(f"# decrypted aggregate = plaintext mean of the {C} clients: {dec.size} values, max |error| {err:.3g}")
         print(f"# every arm wrote the same aggregate: sha256 {digest[:16]}..., {os.path.getsize(p('agg.mkws')) / 1048576.0:.1f} MiB")
     finally:
         if not args.keep:

@@ -99,8 +99,75 @@ static int reads_probe(const char *dir) {
     return 0;
 }
 
+// `pcie_probe reg <dir>`: can the DMA engine read a tmpfs file's pages directly?  mmap(MAP_SHARED) + hipHostRegister of
+// whole files (serial and one thread per file), uploads of 12 MiB blocks straight from the mappings, hipHostUnregister.
+static int reg_probe(const char *dir) {
+    const size_t blk = 12u << 20, per_file = 18, n_files = 8, file_bytes = blk * per_file;
+    std::vector<int> fds;
+    {
+        std::vector<char> src(blk, 7);
+        for (size_t f = 0; f < n_files; ++f) {
+            const std::string path = std::string(dir) + "/probe" + std::to_string(f) + ".bin";
+            const int fd = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+            if (fd < 0) return std::perror("open"), 1;
+            for (size_t b = 0; b < per_file; ++b)
+                if (::pwrite(fd, src.data(), blk, (off_t)(b * blk)) != (ssize_t)blk) return std::perror("pwrite"), 1;
+            fds.push_back(fd);
+            ::unlink(path.c_str());
+        }
+    }
+    char *d = nullptr;
+    CK(hipMalloc(&d, file_bytes * n_files));
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (int mode = 0; mode < 3; ++mode) {  // 0: serial registration, read-only flag; 1: one thread per file; 2: MAP_POPULATE first
+        std::vector<char *> maps(n_files, nullptr);
+        const double t0 = now_ms();
+        for (size_t f = 0; f < n_files; ++f) {
+            void *m = ::mmap(nullptr, file_bytes, PROT_READ | PROT_WRITE, MAP_SHARED | (mode == 2 ? MAP_POPULATE : 0), fds[f], 0);
+            if (m == MAP_FAILED) return std::perror("mmap"), 1;
+            maps[f] = static_cast<char *>(m);
+        }
+        const double t_map = now_ms() - t0;
+        std::atomic<int> failed{0};
+        auto reg = [&](size_t f) {
+            if (hipHostRegister(maps[f], file_bytes, hipHostRegisterDefault) != hipSuccess) failed++;
+        };
+        const double t1 = now_ms();
+        if (mode == 1) {
+            std::vector<std::thread> pool;
+            for (size_t f = 0; f < n_files; ++f) pool.emplace_back(reg, f);
+            for (auto &t : pool) t.join();
+        } else {
+            for (size_t f = 0; f < n_files; ++f) reg(f);
+        }
+        const double t_reg = now_ms() - t1;
+        if (failed) {
+            std::printf("mode %d: hipHostRegister of a tmpfs mapping refused (%s)\n", mode, hipGetErrorString(hipGetLastError()));
+            for (size_t f = 0; f < n_files; ++f) ::munmap(maps[f], file_bytes);
+            continue;
+        }
+        CK(hipDeviceSynchronize());
+        const double t2 = now_ms();
+        for (size_t b = 0; b < per_file; ++b)
+            for (size_t f = 0; f < n_files; ++f)
+                CK(hipMemcpyAsync(d + (f * per_file + b) * blk, maps[f] + b * blk, blk, hipMemcpyHostToDevice, st));
+        CK(hipStreamSynchronize(st));
+        const double t_up = now_ms() - t2;
+        const double t3 = now_ms();
+        for (size_t f = 0; f < n_files; ++f) CK(hipHostUnregister(maps[f]));
+        const double t_unreg = now_ms() - t3;
+        for (size_t f = 0; f < n_files; ++f) ::munmap(maps[f], file_bytes);
+        std::printf("mode %d (%s): mmap %.1f ms, register %zu x %zu MiB %.1f ms, upload %.1f ms = %.1f GB/s, unregister %.1f ms\n", mode,
+                    mode == 0 ? "serial" : mode == 1 ? "one thread per file" : "serial, MAP_POPULATE", t_map, n_files, file_bytes >> 20, t_reg,
+                    t_up, (double)(file_bytes * n_files) / t_up * 1e-6, t_unreg);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc > 2 && std::string(argv[1]) == "reads") return reads_probe(argv[2]);
+    if (argc > 2 && std::string(argv[1]) == "reg") return reg_probe(argv[2]);
     const size_t blk = 12u << 20, n_blk = 128, ring = 16;
     char *d = nullptr;
     CK(hipMalloc(&d, blk * n_blk));

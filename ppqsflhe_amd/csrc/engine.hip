@@ -1667,7 +1667,7 @@ bool Engine::qsum_ok(uint32_t nl) const {
     const int row_h = fast_row(tabs_.log_r2, 1u << tabs_.log_r1);
     if ((row_h != 4 && row_h != 9) || fast_log_h(tabs_.log_r1, 1u << tabs_.log_r2) < 3) return false;
     for (uint32_t k = 0; k < ps_.K; ++k)
-        if (tabs_.h_fp_of[ps_.L + k]) return false;  // k_conv_col_sum takes the P limbs as packed integer sources
+        if (tabs_.h_fp_of[ps_.L + k]) return false;  // k_icol_sum sums the P-limb coefficients as 64-bit integers
     for (uint32_t i = 0; i < nl; ++i)
         if (tabs_.h_fp_of[i]) return true;
     return false;

@@ -1673,7 +1673,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_row3_inner_fp(InnerArgs a, N
 }
 
 // Integer-class Q limb (q_0) of the merged n-client flow: forward row pass of the ModDown conversion SUMMED over the
-// clients (k_conv_col_sum<.., false>: one transform per group instead of one per client), then
+// clients (k_icol_sum + k_conv_col_psum: one conversion and one transform per group instead of one per client), then
 //   out = ( sum_c ctilde_c - conv_sum ) * P^-1 + sum_c c0_c   (component 0; without the c0 term on component 1)
 // with the clients' key-switch accumulators ctilde_c read from the compact til of k_row3_inner_int.  Ring arithmetic mod
 // q throughout, so the residues are those of the per-client chain.  Three-round geometry: 256- and 512-point rows.

@@ -5,15 +5,17 @@
 //     inner products  d_j[t] * b_j[t],  d_j[t] * a_j[t]   (EvalFastKeySwitchCoreExt; the digit that owns t is c1 itself),
 //   * adds c0 * P (component 0),
 // then finishes the forward transform of ApproxModDown's converted limbs -- already summed over the clients in
-// coefficient format by k_conv_col_sum (the transform is linear) -- and subtracts them,
+// coefficient format (k_icol_sum + k_conv_col_psum: the conversion is linear in the INTEGER sum of the clients' canonical
+// coefficients, the transform is linear) -- and subtracts them,
 // keeping the two running sums over digits AND clients in registers as exact doubles; after the last client one
 // multiplication by P^-1 gives  sum_c [ (ctilde_c - conv_c) * P^-1 (+ c0_c) ]  mod q_t, the coefficient-wise sum of the
 // clients' re-encryptions (ReEncrypt x n at changeCipherDomain.cpp:74 + the EvalAdd chain of
 // aggregateEncryptedWeights.cpp:82).  Everything between the products and the final canonical value is ring arithmetic
 // mod q_t, so the stored residues are those of the reference's per-client chain, bit for bit.
 //
-// Against a per-client fused row pass + inner product followed by a tail + sum kernel (rounds 1-2) this removes the round trip of the key-switch accumulators over Q through
-// HBM (2 L limb writes + 2 L limb reads per client ciphertext) and n - 1 of the n multiplications by P^-1.
+// Against a per-client fused row pass + inner product followed by a tail + sum kernel (rounds 1-2) this removes the
+// round trip of the key-switch accumulators over Q through HBM (2 L limb writes + 2 L limb reads per client ciphertext)
+// and n - 1 of the n multiplications by P^-1.
 #pragma once
 #include "ntt_radix.hpp"
 
@@ -25,7 +27,7 @@ namespace mk {
 
 struct QSumArgs {
     const u64 *dig;    // [client][cnt][nparts][ext][N] column-passed converted digits (doubles on fp64-class limbs)
-    const u64 *conv;   // [cnt][2][nl][N]  column-passed ModDown conversions SUMMED over the clients (k_conv_col_sum)
+    const u64 *conv;   // [cnt][2][nl][N]  column-passed ModDown conversions SUMMED over the clients (k_conv_col_psum)
     const u64 *cts;    // input ciphertexts: client c, index i at cts + c * ct_cstride + i * ct_stride, [2][nl][N]
     const u64 *evk;    // client c at evk + c * evk_cstride: [nparts][2][D][N]
     u64 *out;          // index i at out + i * ct_stride_out: [2][nl][N]

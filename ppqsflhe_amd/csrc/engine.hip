@@ -1028,12 +1028,24 @@ static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inve
 template <int LOG_H, int N_IN, int SRCMODE>
 static void launch_conv_col_n(const ConvIo &io, const ConvIo &iof, const dim3 &grid, const dim3 &gridf, const NttTables &T,
                               const DevConv &cv, const Lanes &ln) {
-    launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
-        [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
-            k_conv_col<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE>
-                <<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
-        }); },
-        [&](hipStream_t s) { k_conv_col<LOG_H, N_IN, AR_FP, DevConv, SRCMODE><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
+    if constexpr (N_IN <= 4 && LOG_H >= 3) {
+        // two targets of a class per workgroup (k_conv_col2): half the source traffic through each CU's L1; the last
+        // workgroup of an odd target count carries one
+        const uint32_t per = grid.x / (io.nsel ? io.nsel : 1), perf = gridf.x / (iof.nsel ? iof.nsel : 1);
+        if (io.nsel) with_int_arith(T, [&](auto ar) {
+            k_conv_col2<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE>
+                <<<dim3(per * ((io.nsel + 1) / 2)), NTT_THREADS, 0, ln.main>>>(io, T, cv);
+        });
+        if (iof.nsel)
+            k_conv_col2<LOG_H, N_IN, AR_FP, DevConv, SRCMODE><<<dim3(perf * ((iof.nsel + 1) / 2)), NTT_THREADS, 0, ln.main>>>(iof, T, cv);
+    } else {
+        launch_two_classes(ln, io.nsel != 0, iof.nsel != 0,
+            [&](hipStream_t s) { with_int_arith(T, [&](auto ar) {
+                k_conv_col<LOG_H, N_IN, decltype(ar)::value, DevConv, SRCMODE>
+                    <<<grid, NTT_THREADS, 0, s>>>(io, T, cv);
+            }); },
+            [&](hipStream_t s) { k_conv_col<LOG_H, N_IN, AR_FP, DevConv, SRCMODE><<<gridf, NTT_THREADS, 0, s>>>(iof, T, cv); });
+    }
 }
 template <int LOG_H, int N_IN>
 static void launch_conv_col_m(const ConvIo &io, const ConvIo &iof, const dim3 &grid, const dim3 &gridf, const NttTables &T,

@@ -846,6 +846,75 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col(ConvIo io, NttTable
     else stm.flush<1>(T.stamps, true);
 }
 
+// k_conv_col for TWO targets of one arithmetic class per workgroup (at most 4 sources).  Every target limb's workgroup
+// pulls the same 4 source tiles (128 KiB) through its CU's L1 to produce 32 KiB, and that pull -- not the arithmetic, not
+// the number of loads in flight -- is what the conversion phase waits for (in-kernel stamps: 20-24 k of a wave's 31 k
+// cycles).  Two conversions from one pass over the sources halve it; the second target's 16 words wait in registers
+// while the first goes through its column pass.  Same-box A/B on the step: +1.5 % (integer-class targets), +1.7 %
+// (fp64-class), +3.2 % both (29.64 -> 30.58 k ct/s).  Round 2 and this round's first attempt measured the same idea at
+// -10...-22 %: their kernels spilled.  The last workgroup of an odd target count carries one live target.
+#ifndef MK_CONV2_DEPTH
+#define MK_CONV2_DEPTH 4
+#endif
+template <int LOG_H, int N_IN, int AR, typename CONV, int SRCMODE = 0>
+__global__ __launch_bounds__(NTT_THREADS, 3) void k_conv_col2(ConvIo io, NttTables T, CONV cv) {
+    using TL = ColTile<LOG_H>;
+    constexpr int H = TL::H, S = TL::S;
+    static_assert(N_IN <= 4, "target pairs: at most 4 sources");
+    __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
+    const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
+    const uint32_t groups = io.items * tiles, ntg = (io.nsel + 1) / 2;
+    uint32_t grp, jg;
+    group_member(blockIdx.x, groups, ntg, T.cu_affine, grp, jg);
+    const bool two = jg * 2 + 1 < io.nsel;  // workgroup-uniform
+    const uint32_t jta = nth_set_bit(io.target_mask, jg * 2), jtb = two ? nth_set_bit(io.target_mask, jg * 2 + 1) : jta;
+    uint32_t item, tile;
+    conv_item_tile(grp, groups, io.items, tiles, item, tile);
+    const uint32_t ida = cv.dst_id[jta], idb = cv.dst_id[jtb];
+    const LimbConst la = T.limb[ida], lb = T.limb[idb];
+    if ((la.fp != 0) != (AR == AR_FP) || (lb.fp != 0) != (AR == AR_FP)) return;  // never: the host pairs targets of one class
+    const int c = threadIdx.x % S, j = threadIdx.x / S;
+    const u64 *src = io.in + (size_t)item * io.in_stride + tile * S + c;
+    ConvConst<N_IN> ka, kb;
+    conv_consts<N_IN, AR, SRCMODE>(cv, jta, ka);
+    conv_consts<N_IN, AR, SRCMODE>(cv, jtb, kb);
+    constexpr int DEPTH = MK_CONV2_DEPTH < H ? MK_CONV2_DEPTH : H;  // 4 slices ahead (the one-target kernel: 6)
+    u64 ring[DEPTH][N_IN], xa[H], xb[H];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k)
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i) ring[k][i] = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        u64 p[N_IN];
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i) p[i] = ring[k % DEPTH][i];
+        if (k + DEPTH < H) {
+#pragma unroll
+            for (int i = 0; i < N_IN; ++i)
+                ring[k % DEPTH][i] = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * (k + DEPTH)) * r2];
+        }
+        uint32_t a0[N_IN], a1[N_IN];
+        if (!((AR == AR_FP) && SRCMODE != 0)) conv_split_sources<N_IN, SRCMODE>(p, a0, a1);  // once for both targets
+        xa[k] = conv_output<N_IN, AR, SRCMODE>(p, a0, a1, ka, la);
+        xb[k] = conv_output<N_IN, AR, SRCMODE>(p, a0, a1, kb, lb);
+        // materialised here (see k_conv_col): this is what makes two targets fit -- 115-117 VGPRs and no scratch, 4 waves
+        // per SIMD like the one-target kernel; without it the compiler parked 34-150 registers in scratch
+        asm volatile("" : "+v"(xa[k]), "+v"(xb[k]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jta] * n + tile * S + c;
+    col_forward_finish<LOG_H, AR>(xa, lds, T.tw + (size_t)ida * n, T.tw_sh + (size_t)ida * n, la, j, c, dst, r2);
+    if (!two) return;
+    __syncthreads();  // the first target's exchange is read out
+    dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jtb] * n + tile * S + c;
+    // the second pass's twiddle loads must not be hoisted above the first pass (60 more live registers): its table
+    // pointers are opaque until here
+    const u64 *twb = T.tw + (size_t)idb * n, *twb_sh = T.tw_sh + (size_t)idb * n;
+    asm volatile("" : "+s"(twb), "+s"(twb_sh));
+    col_forward_finish<LOG_H, AR>(xb, lds, twb, twb_sh, lb, j, c, dst, r2);
+}
+
 // ---- ApproxModDown's conversion P -> Q_l for a whole group of clients at once ------------------------------------------
 // The reference converts every client's key-switch result on its own (ApproxModDown inside each ReEncrypt) and adds the
 // re-encryptions afterwards (EvalAdd).  With x_{c,k} the canonical residue mod p_k of client c's coefficient (the inverse

@@ -35,7 +35,7 @@ def alg_limbs(name):
     if k == "k_switch_col":
         t = (nfp - 1) if a[1] == "1" else 1
         return polys2, t * polys2
-    if k == "k_conv_col":                                           # a = LOG_H, N_IN, AR, DevConv, SRCMODE
+    if k in ("k_conv_col", "k_conv_col2"):                          # a = LOG_H, N_IN, AR, DevConv, SRCMODE (col2: two targets per workgroup)
         digits = [0] if a[4] == "2" else [1, 2]
         tg = fp_t if a[2] == "1" else int_t
         return sum(ALPHA * items for _ in digits), sum(tg[j] * items for j in digits)

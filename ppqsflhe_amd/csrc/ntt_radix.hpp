@@ -1066,6 +1066,63 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void k_conv_col_psum(ConvIo io, Ntt
     col_forward_finish<LOG_H, AR>(x, lds, T.tw + (size_t)id * n, T.tw_sh + (size_t)id * n, lc, j, c, dst, r2);
 }
 
+// k_conv_col_psum for TWO fp64-class targets per workgroup (see k_conv_col2: one pass over the K source tiles feeds both
+// conversions; the last workgroup of an odd target count carries one).  This is the instance the fp64-class targets run;
+// k_conv_col_psum itself serves the integer-class ones (q_0: a single target).
+template <int LOG_H, int N_IN, typename CONV>
+__global__ __launch_bounds__(NTT_THREADS, 3) void k_conv_col_psum2(ConvIo io, NttTables T, CONV cv) {
+    using TL = ColTile<LOG_H>;
+    constexpr int H = TL::H, S = TL::S;
+    __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
+    const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
+    const uint32_t groups = io.items * tiles, ntg = (io.nsel + 1) / 2;
+    uint32_t grp, jg;
+    group_member(blockIdx.x, groups, ntg, T.cu_affine, grp, jg);
+    const bool two = jg * 2 + 1 < io.nsel;  // workgroup-uniform
+    const uint32_t jta = nth_set_bit(io.target_mask, jg * 2), jtb = two ? nth_set_bit(io.target_mask, jg * 2 + 1) : jta;
+    uint32_t item, tile;
+    conv_item_tile(grp, groups, io.items, tiles, item, tile);
+    const uint32_t ida = cv.dst_id[jta], idb = cv.dst_id[jtb];
+    const LimbConst la = T.limb[ida], lb = T.limb[idb];
+    if (la.fp == 0 || lb.fp == 0) return;  // never: the host pairs fp64-class targets
+    const int c = threadIdx.x % S, j = threadIdx.x / S;
+    const u64 *src = io.in + (size_t)item * io.in_stride + tile * S + c;
+    double hda[N_IN], hqa[N_IN], hdb[N_IN], hqb[N_IN];
+#pragma unroll
+    for (int i = 0; i < N_IN; ++i) {
+        hda[i] = cv.hat_d[i * cv.n_out + jta];
+        hqa[i] = cv.hatq_d[i * cv.n_out + jta];
+        hdb[i] = cv.hat_d[i * cv.n_out + jtb];
+        hqb[i] = cv.hatq_d[i * cv.n_out + jtb];
+    }
+    const double c32a = (double)reduce_word(1ull << 32, la), c32qa = c32a * la.qinv;  // see k_conv_col_psum
+    const double c32b = (double)reduce_word(1ull << 32, lb), c32qb = c32b * lb.qinv;
+    u64 xa[H], xb[H];
+#pragma unroll
+    for (int kk = 0; kk < H; ++kk) {
+        double acca = 0.0, accb = 0.0;
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i) {
+            const u64 p = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * kk) * r2];
+            const double hi = (double)(uint32_t)(p >> 32), lo = (double)(uint32_t)p;
+            acca += fp_mulmod(fp_mulmod(hi, c32a, c32qa, la.qd) + lo, hda[i], hqa[i], la.qd);
+            accb += fp_mulmod(fp_mulmod(hi, c32b, c32qb, lb.qd) + lo, hdb[i], hqb[i], lb.qd);
+        }
+        xa[kk] = dbits(fp_reduce(acca, la.qd, la.qinv));
+        xb[kk] = dbits(fp_reduce(accb, lb.qd, lb.qinv));
+        asm volatile("" : "+v"(xa[kk]), "+v"(xb[kk]));  // materialised here (see k_conv_col)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jta] * n + tile * S + c;
+    col_forward_finish<LOG_H, AR_FP>(xa, lds, T.tw + (size_t)ida * n, T.tw_sh + (size_t)ida * n, la, j, c, dst, r2);
+    if (!two) return;
+    __syncthreads();  // the first target's exchange is read out
+    dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jtb] * n + tile * S + c;
+    const u64 *twb = T.tw + (size_t)idb * n, *twb_sh = T.tw_sh + (size_t)idb * n;
+    asm volatile("" : "+s"(twb), "+s"(twb_sh));  // not hoisted above the first pass
+    col_forward_finish<LOG_H, AR_FP>(xb, lds, twb, twb_sh, lb, j, c, dst, r2);
+}
+
 // DropLastElementAndScale, first half fused: NativeVectorT::SwitchModulus of the dropped limb (COEFFICIENT format,
 // canonical; centred lift: v > floor(q_last / 2) is negative) into a remaining limb + the forward column pass of that
 // limb -- the switched polynomial never goes to HBM in coefficient form.  last: [items][N]; out: [items][nl-1][N]

@@ -45,6 +45,8 @@ def alg_limbs(name):
         return (BETA - 1) * items + items + BETA * 2 * C, 2 * items
     if k == "k_icol_sum":
         return 2 * K * items, K * polys2
+    if k == "k_conv_col_psum2":                                     # fp64-class targets, two per workgroup
+        return K * polys2, nfp * polys2
     if k == "k_conv_col_psum":
         return K * polys2, (nfp if a[2] == "1" else 1) * polys2
     if k == "k_conv_col_sum2" or k == "k_conv_col_sum":            # round 2's per-client summed conversion

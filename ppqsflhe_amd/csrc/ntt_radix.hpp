@@ -2030,12 +2030,25 @@ __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_
         wave_lds_sync();
         const u64 *e0 = evk + (((size_t)dj * 2 + 0) * a.D + id) * n + tile_off;
         const u64 *e1 = evk + (((size_t)dj * 2 + 1) * a.D + id) * n + tile_off;
+        ulong2 eb[PAIRS], ec[PAIRS];
+        // the digit's eval-key tiles in one burst (see k_qsum3_fp; +0.2 % on the step) in the 2-wave P instance, which has the
+        // registers; the 3-wave instance would park 14 more in scratch
+        constexpr bool BURST = INVP;
+        if (BURST) {
+#pragma unroll
+            for (int i = 0; i < PAIRS; ++i) {
+                const int e = row3_pair<LOGC>(c.g, c.t, i);
+                eb[i] = reinterpret_cast<const ulong2 *>(e0)[e];
+                ec[i] = reinterpret_cast<const ulong2 *>(e1)[e];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
             const int e = row3_pair<LOGC>(c.g, c.t, i);
             const int xx = (2 * e) % R;
-            const ulong2 b = reinterpret_cast<const ulong2 *>(e0)[e];
-            const ulong2 cc = reinterpret_cast<const ulong2 *>(e1)[e];
+            const ulong2 b = BURST ? eb[i] : reinterpret_cast<const ulong2 *>(e0)[e];
+            const ulong2 cc = BURST ? ec[i] : reinterpret_cast<const ulong2 *>(e1)[e];
             const u64 yx = lds[TL::at(c.g, xx)], yz = lds[TL::at(c.g, xx + 1)];
             mac128(h0[2 * i], l0[2 * i], yx, b.x);
             mac128(h0[2 * i + 1], l0[2 * i + 1], yz, b.y);

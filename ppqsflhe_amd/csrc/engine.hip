@@ -1028,7 +1028,7 @@ static void ntt_passes(NttIo io, const NttTables &T, uint32_t n_polys, bool inve
 template <int LOG_H, int N_IN, int SRCMODE>
 static void launch_conv_col_n(const ConvIo &io, const ConvIo &iof, const dim3 &grid, const dim3 &gridf, const NttTables &T,
                               const DevConv &cv, const Lanes &ln) {
-    if constexpr (N_IN <= 4 && LOG_H >= 3) {
+    if constexpr (LOG_H >= 3) {
         // two targets of a class per workgroup (k_conv_col2): half the source traffic through each CU's L1; the last
         // workgroup of an odd target count carries one
         const uint32_t per = grid.x / (io.nsel ? io.nsel : 1), perf = gridf.x / (iof.nsel ? iof.nsel : 1);

@@ -860,7 +860,7 @@ template <int LOG_H, int N_IN, int AR, typename CONV, int SRCMODE = 0>
 __global__ __launch_bounds__(NTT_THREADS, 3) void k_conv_col2(ConvIo io, NttTables T, CONV cv) {
     using TL = ColTile<LOG_H>;
     constexpr int H = TL::H, S = TL::S;
-    static_assert(N_IN <= 4, "target pairs: at most 4 sources");
+    static_assert(SRCMODE == 0 || N_IN <= 4, "double sources: at most 4 per digit");
     __shared__ u64 lds[TL::WORDS + ColTwB<LOG_H>::WORDS];
     const uint32_t n = 1u << T.log_n, r2 = 1u << T.log_r2, tiles = r2 / S;
     const uint32_t groups = io.items * tiles, ntg = (io.nsel + 1) / 2;
@@ -875,11 +875,39 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_conv_col2(ConvIo io, NttTabl
     if ((la.fp != 0) != (AR == AR_FP) || (lb.fp != 0) != (AR == AR_FP)) return;  // never: the host pairs targets of one class
     const int c = threadIdx.x % S, j = threadIdx.x / S;
     const u64 *src = io.in + (size_t)item * io.in_stride + tile * S + c;
+    u64 xa[H], xb[H];
+    if constexpr (N_IN > 4) {
+        // 5..8 sources (e.g. alpha = K = 7 at L = 20): 30-bit columns with the middle one split in two, as in k_conv_col
+        uint32_t h0a[N_IN], h1a[N_IN], h0b[N_IN], h1b[N_IN];
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i) {
+            split30(cv.hat[i * cv.n_out + jta], h0a[i], h1a[i]);
+            split30(cv.hat[i * cv.n_out + jtb], h0b[i], h1b[i]);
+        }
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            Cols4 acca{0, 0, 0, 0}, accb{0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < N_IN; ++i) {
+                const u64 p = src[(size_t)cv.src_slot[i] * n + (size_t)(j + H * k) * r2];
+                mac_cols4(acca, (uint32_t)p, (uint32_t)(p >> 32), h0a[i], h1a[i]);
+                mac_cols4(accb, (uint32_t)p, (uint32_t)(p >> 32), h0b[i], h1b[i]);
+            }
+            xa[k] = reduce_cols4(acca, la);
+            xb[k] = reduce_cols4(accb, lb);
+            if (AR == AR_FP) {
+                xa[k] = dbits(fp_reduce((double)xa[k], la.qd, la.qinv));
+                xb[k] = dbits(fp_reduce((double)xb[k], lb.qd, lb.qinv));
+            }
+            asm volatile("" : "+v"(xa[k]), "+v"(xb[k]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     ConvConst<N_IN> ka, kb;
     conv_consts<N_IN, AR, SRCMODE>(cv, jta, ka);
     conv_consts<N_IN, AR, SRCMODE>(cv, jtb, kb);
     constexpr int DEPTH = MK_CONV2_DEPTH < H ? MK_CONV2_DEPTH : H;  // 4 slices ahead (the one-target kernel: 6)
-    u64 ring[DEPTH][N_IN], xa[H], xb[H];
+    u64 ring[DEPTH][N_IN];
 #pragma unroll
     for (int k = 0; k < DEPTH; ++k)
 #pragma unroll
@@ -902,6 +930,7 @@ __global__ __launch_bounds__(NTT_THREADS, 3) void k_conv_col2(ConvIo io, NttTabl
         // per SIMD like the one-target kernel; without it the compiler parked 34-150 registers in scratch
         asm volatile("" : "+v"(xa[k]), "+v"(xb[k]));
         __builtin_amdgcn_sched_barrier(0);
+    }
     }
     u64 *dst = io.out + (size_t)item * io.out_stride + (size_t)cv.dst_slot[jta] * n + tile * S + c;
     col_forward_finish<LOG_H, AR>(xa, lds, T.tw + (size_t)ida * n, T.tw_sh + (size_t)ida * n, la, j, c, dst, r2);

@@ -1779,8 +1779,11 @@ void Engine::reencrypt_sum_merged(const u64 *cts, const u64 *evks, u64 *out, uin
             }
             QSumArgs qa{dig, convsum, ct0, evk0, out + (size_t)b0 * ct_words, pq, ct_cstride, ct_words, evk_words, ct_words,
                         gc, cnt, nl, ext, D, ps_.alpha, fp_mask, (uint32_t)__builtin_popcountll(fp_mask), g0 != 0 ? 1u : 0u};
+            // 256-point rows: 2 workgroups per CU -- at N = 2^16, L = 12 the kernel's 5 632 workgroups then fill the 512 resident
+            // slots exactly 11 times (7.33 times 768 at 3 per CU: a last round a third full) and nothing is parked in scratch;
+            // +0.45 % on the step after the eval-key bursts (it was +-0 before them)
             if (wide_rows) launch_qsum3_fp<3, 3>(qa, tabs_, nparts, main);
-            else launch_qsum3_fp<2, 3>(qa, tabs_, nparts, main);
+            else launch_qsum3_fp<2, 2>(qa, tabs_, nparts, main);
             MK_HIP(hipGetLastError());
         }
     }

@@ -1986,8 +1986,11 @@ MK_D void row3_inverse_int(u64 (&x)[8], const Row3Ctx &c, const u64 (&wc)[7], co
 #ifndef MK_INVP_WAVES
 #define MK_INVP_WAVES 2  // 168 VGPRs would spill 19 registers in the P instance; 2 waves measured +0.7 %
 #endif
+#ifndef MK_INNERQ_WAVES
+#define MK_INNERQ_WAVES 2  // the q_0 instance too: no scratch (9 registers at 3 waves), 4 096 workgroups = 8 rounds of 512 slots, +0.36 %
+#endif
 template <int NPARTS, int LOGC, bool INVP, int AR>
-__global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_inner_int(InnerArgs a, NttTables T, uint32_t L, u64 *pc,
+__global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : MK_INNERQ_WAVES) void k_row3_inner_int(InnerArgs a, NttTables T, uint32_t L, u64 *pc,
                                                                    uint32_t K) {
     using TL = RowT<LOGC>;
     constexpr int R = TL::R, S = TL::ROWS, TPR = TL::TPR, PAIRS = 4;
@@ -2060,9 +2063,9 @@ __global__ __launch_bounds__(NTT_THREADS, INVP ? MK_INVP_WAVES : 3) void k_row3_
         const u64 *e0 = evk + (((size_t)dj * 2 + 0) * a.D + id) * n + tile_off;
         const u64 *e1 = evk + (((size_t)dj * 2 + 1) * a.D + id) * n + tile_off;
         ulong2 eb[PAIRS], ec[PAIRS];
-        // the digit's eval-key tiles in one burst (see k_qsum3_fp; +0.2 % on the step) in the 2-wave P instance, which has the
-        // registers; the 3-wave instance would park 14 more in scratch
-        constexpr bool BURST = INVP;
+        // the digit's eval-key tiles in one burst (see k_qsum3_fp; +0.2 % on the step) in the 2-wave instances, which have the
+        // registers; a 3-wave instance would park 14 more in scratch
+        constexpr bool BURST = INVP ? MK_INVP_WAVES == 2 : MK_INNERQ_WAVES == 2;
         if (BURST) {
 #pragma unroll
             for (int i = 0; i < PAIRS; ++i) {
